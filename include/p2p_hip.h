@@ -1,0 +1,130 @@
+/*
+ * libp2p_hip -- MI355X (gfx950) implementation of the Patch2Pix matching hot path.
+ *
+ * C ABI, plain pointers and sizes only.  The reference (GrumpyZhou/patch2pix) has no FFI: its
+ * boundary for this path is the Python module API (networks/patch2pix.py, utils/eval/model_helper.py).
+ * Each entry point below names the reference function(s) it replaces; the Python side
+ * (patch2pix_amd/) binds them with ctypes and re-exposes the reference's own names.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative P2P_E* code; p2p_last_error() returns a
+ *     thread-local message for the last failure on the calling thread;
+ *   - "device pointer" arguments are caller-owned HBM buffers (torch tensors); nothing is retained
+ *     across calls except the opaque weight handles;
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - dense tensors are contiguous fp32 in the layout PyTorch produces (NCHW without the N);
+ *   - match rows are (xA, yA, xB, yB).
+ */
+#ifndef P2P_HIP_H
+#define P2P_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P2P_OK            0
+#define P2P_EINVAL       -1   /* bad argument (null pointer, size not supported ...) */
+#define P2P_EHIP         -2   /* a HIP runtime call failed */
+#define P2P_EUNSUPPORTED -3   /* valid for the reference but not implemented by this library */
+#define P2P_ENOMEM       -4   /* workspace too small / allocation failed */
+
+typedef void *p2p_stream_t;                 /* hipStream_t */
+typedef struct p2p_ncn p2p_ncn;             /* NCNet consensus filters, device resident */
+typedef struct p2p_regressor p2p_regressor; /* one FeatRegressNet, packed + device resident */
+
+int p2p_version(void);
+const char *p2p_last_error(void);
+
+/* ---- weights ------------------------------------------------------------------------------- */
+
+/* NeighConsensus(kernel_sizes=[3,3], channels=[16,1]) -- reference networks/ncn/model.py:124-143,
+ * built at networks/patch2pix.py:32.  HOST pointers to the checkpoint tensors in their stored
+ * (pre-permuted, networks/ncn/conv4d.py:119-120) layout:
+ *   w1 [3,16,1,3,3,3]  b1 [16]  w2 [3,1,16,3,3,3]  b2 [1]                                     */
+int p2p_ncn_create(const float *w1, const float *b1, const float *w2, const float *b2, p2p_ncn **out);
+void p2p_ncn_destroy(p2p_ncn *ncn);
+
+/* FeatRegressNet with the released configuration (conv_kers [3,3], conv_strs [2,1],
+ * conv_dims [512,512], fc_dims [512,256], feat_comb 'pre', psize 16, feat_idx [0,1,2,3]) --
+ * reference networks/modules.py:56-112.  HOST pointers to the state_dict tensors.           */
+typedef struct p2p_bn_params {
+    const float *weight, *bias, *running_mean, *running_var;
+} p2p_bn_params;
+
+typedef struct p2p_regressor_params {
+    const float *conv1_w;      /* conv.0.weight [512,518,3,3] */
+    p2p_bn_params bn1;         /* conv.1.*      [512]         */
+    const float *conv2_w;      /* conv.2.weight [512,512,3,3] */
+    p2p_bn_params bn2;         /* conv.3.*      [512]         */
+    const float *fc1_w, *fc1_b; /* fc.0 [512,512],[512]       */
+    p2p_bn_params bnf1;        /* fc.1.*        [512]         */
+    const float *fc2_w, *fc2_b; /* fc.3 [256,512],[256]       */
+    p2p_bn_params bnf2;        /* fc.4.*        [256]         */
+    const float *fc3_w, *fc3_b; /* fc.6 [5,256],[5]           */
+} p2p_regressor_params;
+
+int p2p_regressor_create(const p2p_regressor_params *params, p2p_regressor **out);
+void p2p_regressor_destroy(p2p_regressor *reg);
+
+/* ---- coarse stage ---------------------------------------------------------------------------- */
+
+/* Workspace (bytes) p2p_coarse_forward needs for these sizes. */
+size_t p2p_coarse_workspace_bytes(int channels, int hA, int wA, int hB, int wB, int ksize);
+
+/* Patch2Pix.forward_coarse_match -- reference networks/patch2pix.py:120-136:
+ * L2Normalize (modules.py:6) -> FeatCorrelation (modules.py:41-53) -> maxpool4d (modules.py:11-34,
+ * only if ksize > 1) -> MutualMatching (ncn/model.py:157-176) -> NeighConsensus (ncn/model.py:145-155,
+ * conv4d.py:12-74) -> MutualMatching.
+ *   featA [C,hA,wA], featB [C,hB,wB]      device, fp32
+ *   corr4d_out [hA/k, wA/k, hB/k, wB/k]   device, fp32
+ *   delta_out  same shape, uint8, value s = ((di*k+dj)*k+dk)*k+dl of the first maximum in the
+ *              reference's slice order (modules.py:13-18); may be NULL; ignored when ksize == 1
+ * ksize must be 1 or 2 (the reference default; other values -> P2P_EUNSUPPORTED).               */
+int p2p_coarse_forward(const float *featA, const float *featB, int channels, int hA, int wA, int hB, int wB,
+                       int ksize, const p2p_ncn *ncn, float *corr4d_out, uint8_t *delta_out,
+                       void *workspace, size_t workspace_bytes, p2p_stream_t stream);
+
+/* Expand the packed relocalisation byte into the reference's four int64 tensors
+ * (max_i, max_j, max_k, max_l of modules.py:24-28); `out` holds 4 consecutive planes of n int64. */
+int p2p_delta_unpack(const uint8_t *delta, size_t n, int ksize, int64_t *out, p2p_stream_t stream);
+
+/* Patch2Pix.cal_coarse_matches -- reference networks/patch2pix.py:340-375, i.e. corr_to_matches in
+ * both directions (ncn/extract_ncmatches.py:6-94: softmax along one side, max/first-argmax,
+ * relocalisation with delta) concatenated B->A first then A->B, scaled to pixels:
+ *   matches_out [nB + nA, 4] int64 = upsample * (xA,yA,xB,yB) (+ upsample/2 if center)
+ *   scores_out  [nB + nA]    fp32                                    (nA = hA'*wA', nB = hB'*wB')
+ * corr4d dims are the pooled ones; delta may be NULL (ksize 1).                                  */
+int p2p_coarse_matches(const float *corr4d, const uint8_t *delta, int hA, int wA, int hB, int wB, int ksize,
+                       int upsample, int center, int64_t *matches_out, float *scores_out, p2p_stream_t stream);
+
+/* ---- fine stage ------------------------------------------------------------------------------ */
+
+/* One image's feature pyramid levels feat_idx [0,1,2,3] (reference networks/resnet.py:138-157 with
+ * change_stride): device pointers [3,H,W], [64,H/2,W/2], [64,H/4,W/4], [128,H/8,W/8].         */
+typedef struct p2p_pyramid {
+    const float *level[4];
+    int height, width;      /* of level 0 (the network input); multiples of 8 */
+} p2p_pyramid;
+
+/* Patch2Pix.forward_fine_match for one batch item -- reference networks/patch2pix.py:157-218:
+ * select_local_patch_feats (networks/utils.py:4-36) -> L2Normalize(dim 0) -> FeatRegressNet
+ * (modules.py:101-112) -> parse_regressor_out (patch2pix.py:138-155).
+ * With reg2 != NULL the second regressor is run on the first one's output inside the same launch
+ * (predict_fine's mid -> fine chain, patch2pix.py:259-272).
+ *   proposals   [n,4] int64 (is_float == 0) or fp32 (is_float != 0), device
+ *   matches1/probs1 [n,4]/[n] fp32 outputs of reg1 (may be NULL when reg2 != NULL)
+ *   matches2/probs2 outputs of reg2 (required when reg2 != NULL)
+ *   raw1/raw2   optional [n,5] raw regressor outputs (NULL to skip)                             */
+int p2p_regress(const p2p_regressor *reg1, const p2p_regressor *reg2,
+                const p2p_pyramid *im1, const p2p_pyramid *im2,
+                const void *proposals, int is_float, int n,
+                float *matches1, float *probs1, float *raw1,
+                float *matches2, float *probs2, float *raw2, p2p_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P2P_HIP_H */

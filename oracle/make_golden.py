@@ -110,7 +110,7 @@ def case_estimate_matches(ref, name, seed, H, W, imsize):
             m, s, c = ref.model_helper.estimate_matches(net, os.path.join(td, "1.png"), os.path.join(td, "2.png"),
                                                         ksize=2, imsize=imsize, **kw)
             res[tag + "_matches"], res[tag + "_scores"], res[tag + "_coarse"] = m, s, c
-    np.savez_compressed(os.path.join(GOLDEN, name), seed=seed, H=H, W=W, imsize=imsize, sd_seed=SD_SEED,
+    np.savez_compressed(os.path.join(GOLDEN, name), seed=seed, H=H, W=W, imsize=(-1 if imsize is None else imsize), sd_seed=SD_SEED,
                         input_checksum=float(im1.astype(np.float64).sum() + im2.astype(np.float64).sum()), **res)
     print(name, "fine", res["fine_matches"].shape, res["fine_matches"].dtype, res["fine_scores"].dtype,
           "coarse", res["coarse_matches"].shape)

@@ -1,0 +1,15 @@
+// Library-wide pieces of the C ABI: version and thread-local error string.
+#include "p2p_common.h"
+
+namespace p2p {
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace p2p
+
+extern "C" int p2p_version(void) { return 100; }
+extern "C" const char *p2p_last_error(void) { return p2p::g_err; }

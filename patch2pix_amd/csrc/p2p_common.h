@@ -1,0 +1,65 @@
+// Shared declarations for libp2p_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include "../../include/p2p_hip.h"
+
+namespace p2p {
+
+void set_error(const char *fmt, ...);
+
+#define P2P_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            p2p::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return P2P_EHIP;                                                             \
+        }                                                                                \
+    } while (0)
+
+#define P2P_REQUIRE(cond, code, ...)                                                     \
+    do {                                                                                 \
+        if (!(cond)) {                                                                   \
+            p2p::set_error(__VA_ARGS__);                                                 \
+            return (code);                                                               \
+        }                                                                                \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Check the launch that was just issued (asynchronous errors surface at the next sync).
+static inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+        return P2P_EHIP;
+    }
+    return P2P_OK;
+}
+
+}  // namespace p2p
+
+// opaque handles -------------------------------------------------------------------------------
+struct p2p_ncn {
+    float *dev;        // one device allocation holding everything below
+    float *w1cat;      // [81][32]  layer-1 taps x (16 direct-branch + 16 transposed-branch) channels
+    float *b1cat;      // [32]
+    float *w2cat;      // [32][81]  layer-2: channels 0-15 direct branch, 16-31 transposed branch
+    float b2;          // scalar bias of layer 2 (same for both branches)
+};
+
+struct p2p_regressor {
+    float *dev;        // one device allocation
+    const float *wp1;  // conv1 weights, MFMA-fragment order [8 waves][585 chunks][2][64 lanes][4]
+    const float *wp2;  // conv2 weights,                    [8][576][2][64][4]
+    const float *bn1s, *bn1b;   // folded BN scale/shift [512]
+    const float *bn2s, *bn2b;   // [512]
+    const float *fc1t, *fc1b, *bnf1s, *bnf1b;   // fc1 as [128][512][4]; [512]
+    const float *fc2t, *fc2b, *bnf2s, *bnf2b;   // fc2 as [128][256][4]; [256]
+    const float *fc3, *fc3b;                    // [5][256]; [5]
+};

@@ -1,0 +1,524 @@
+// Fine stage of the Patch2Pix matching path on gfx950: one workgroup per proposal runs
+//   patch gather (4 pyramid levels, both images) -> per-pixel L2 normalisation ->
+//   conv 3x3 s2 (518->512) -> BN -> conv 3x3 s1 (512->512) -> BN -> ReLU -> 8x8 max ->
+//   FC 512 -> 512 -> 256 -> 5 -> tanh/sigmoid parse -> clamp
+// and, when a second regressor is given, feeds its own result through that one as well.
+//
+// Reference semantics: networks/utils.py:4-36 (gather), networks/patch2pix.py:157-184 (mini batch),
+// networks/modules.py:56-112 (FeatRegressNet), networks/patch2pix.py:138-155 (parse).
+//
+// Mapping to CDNA4
+//   * a proposal is a 64-row (8x8 output pixels) implicit GEMM against 512 output channels; the
+//     8 waves of the workgroup each own 64 output channels (2x2 tiles of v_mfma_f32_32x32x2_f32),
+//     so the 16x16x259x2 patch is never written to HBM and the 512x8x8 intermediate lives in LDS;
+//   * the A operand comes from LDS: the patch is stored *deduplicated* (levels 1-3 are nearest
+//     neighbour up-samplings, so a 16x16 window only touches 9x9 / 5x5 / 3x3 distinct cells) and
+//     the per-pixel L2 scale is applied when the fragment is read;
+//   * the B operand (weights) is streamed straight from L2 into VGPRs in a layout packed at load
+//     time in exact consumption order: one global_load_dwordx4 per lane feeds four k-steps;
+//   * fp32 MFMA is bit-identical to an fma chain, so results match an fp32 CPU evaluation to
+//     round-off of the (fixed, documented) summation order: taps outer, channels inner.
+#include "p2p_common.h"
+
+#include <cmath>
+#include <vector>
+
+namespace p2p {
+
+constexpr int NT = 512;                 // threads per workgroup (8 waves)
+constexpr int K1_CHUNKS_PER_TAP = 65;   // 1 (level-0 of both images, 6 ch padded to 8) + 2*(8+8+16)
+constexpr int K1_CHUNKS = 9 * K1_CHUNKS_PER_TAP;
+constexpr int K2_CHUNKS_PER_TAP = 64;   // 512 channels / 8
+constexpr int K2_CHUNKS = 9 * K2_CHUNKS_PER_TAP;
+constexpr int WP1_FLOATS = 8 * (K1_CHUNKS + 1) * 2 * 64 * 4;   // +1 chunk: the prefetch runs one ahead
+constexpr int WP2_FLOATS = 8 * (K2_CHUNKS + 1) * 2 * 64 * 4;
+
+// LDS carve-up (floats)
+constexpr int TILE_L0 = 0, TILE_L1 = 768, TILE_L2 = 5952, TILE_L3 = 7552, TILE_IMG = 8704;
+constexpr int HSTRIDE = 68;                       // row stride of the conv1 output H[c][64 px]
+constexpr int LDS_UNION = 512 * HSTRIDE;          // max(2*TILE_IMG, 512*HSTRIDE)
+constexpr int LDS_SCALE = LDS_UNION;              // [2][256] per-pixel 1/||f||
+constexpr int LDS_V = LDS_SCALE + 512;            // [512] pooled conv features
+constexpr int LDS_F1 = LDS_V + 512;               // [512]
+constexpr int LDS_F2 = LDS_F1 + 512;              // [256]
+constexpr int LDS_MISC = LDS_F2 + 256;            // [16] raw outputs / current proposal
+constexpr int LDS_FLOATS = LDS_MISC + 16;
+constexpr size_t LDS_BYTES = size_t(LDS_FLOATS) * 4;
+
+struct RegDev {
+    const float *wp1, *wp2, *bn1s, *bn1b, *bn2s, *bn2b;
+    const float *fc1t, *fc1b, *bnf1s, *bnf1b, *fc2t, *fc2b, *bnf2s, *bnf2b, *fc3, *fc3b;
+};
+
+struct RegressArgs {
+    const float *pyr[2][4];
+    int H[2], W[2];
+    const void *proposals;
+    int is_float, n, nlevels;
+    RegDev reg[2];
+    float *matches[2], *probs[2], *raw[2];
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// One chunk = 8 K values = 4 k-steps for both m-tiles and both n-tiles (16 MFMAs).
+#define P2P_CHUNK_MFMA(A0, A1)                                   \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {              \
+        acc00 = MFMA(A0[q], b0[q], acc00);                       \
+        acc01 = MFMA(A0[q], b1[q], acc01);                       \
+        acc10 = MFMA(A1[q], b0[q], acc10);                       \
+        acc11 = MFMA(A1[q], b1[q], acc11);                       \
+    }
+
+__global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    const int prop = blockIdx.x;
+
+    float *tiles = smem;
+    float *Hbuf = smem;
+    float *scale = smem + LDS_SCALE;
+    float *V = smem + LDS_V;
+    float *F1 = smem + LDS_F1;
+    float *F2 = smem + LDS_F2;
+    float *misc = smem + LDS_MISC;
+
+    // current proposal (float coordinates; exact for the int64 coarse matches)
+    if (tid < 4) {
+        float v;
+        if (args.is_float) v = ((const float *)args.proposals)[prop * 4 + tid];
+        else v = (float)((const long long *)args.proposals)[prop * 4 + tid];
+        misc[8 + tid] = v;
+    }
+    __syncthreads();
+
+    for (int lvl = 0; lvl < args.nlevels; ++lvl) {
+        const RegDev &R = args.reg[lvl];
+        // ---------------------------------------------------------------- proposal geometry
+        // x, y = trunc(match) (networks/utils.py:19); window origin = centre - 8 (:8-15)
+        int x0[2], y0[2];
+        x0[0] = (int)misc[8 + 0] - 8; y0[0] = (int)misc[8 + 1] - 8;
+        x0[1] = (int)misc[8 + 2] - 8; y0[1] = (int)misc[8 + 3] - 8;
+        __syncthreads();   // everyone has read misc / finished with the previous level's LDS
+
+        // ---------------------------------------------------------------- gather (dedup tiles)
+        for (int img = 0; img < 2; ++img) {
+            const int Hh = args.H[img], Ww = args.W[img];
+            float *t = tiles + img * TILE_IMG;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int Rr = (j == 0) ? 16 : (j == 1) ? 9 : (j == 2) ? 5 : 3;
+                const int Cc = (j == 0) ? 3 : (j == 3) ? 128 : 64;
+                const int off = (j == 0) ? TILE_L0 : (j == 1) ? TILE_L1 : (j == 2) ? TILE_L2 : TILE_L3;
+                const int Hj = Hh >> j, Wj = Ww >> j;
+                const int r0 = clampi(y0[img] >> j, 0, Hj - 1);
+                const int c0 = clampi(x0[img] >> j, 0, Wj - 1);
+                const float *src = args.pyr[img][j];
+                for (int e = tid; e < Cc * Rr * Rr; e += NT) {
+                    const int c = e / (Rr * Rr);
+                    const int rem = e - c * (Rr * Rr);
+                    const int r = rem / Rr;
+                    const int cc = rem - r * Rr;
+                    const int sy = min(r0 + r, Hj - 1);
+                    const int sx = min(c0 + cc, Wj - 1);
+                    t[off + e] = src[((size_t)c * Hj + sy) * Wj + sx];
+                }
+            }
+        }
+        __syncthreads();
+
+        // cell index of patch row/col `p` (0..15) at level j, relative to the tile origin
+        auto cell = [&](int origin, int p, int j, int dim) -> int {
+            const int d = dim >> j;
+            return clampi((origin + p) >> j, 0, d - 1) - clampi(origin >> j, 0, d - 1);
+        };
+
+        // ---------------------------------------------------------------- per-pixel L2 scale
+        {
+            const int img = tid >> 8, pix = tid & 255, py = pix >> 4, px = pix & 15;
+            const float *t = tiles + img * TILE_IMG;
+            float ss = 0.f;
+            {
+                const float *p = t + TILE_L0 + py * 16 + px;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { float v = p[c * 256]; ss = fmaf(v, v, ss); }
+            }
+#pragma unroll
+            for (int j = 1; j < 4; ++j) {
+                const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
+                const int Cc = (j == 3) ? 128 : 64;
+                const int off = (j == 1) ? TILE_L1 : (j == 2) ? TILE_L2 : TILE_L3;
+                const float *p = t + off + cell(y0[img], py, j, args.H[img]) * Rr + cell(x0[img], px, j, args.W[img]);
+                for (int c = 0; c < Cc; ++c) { float v = p[c * Rr * Rr]; ss = fmaf(v, v, ss); }
+            }
+            scale[tid] = 1.0f / sqrtf(ss + 1e-6f);
+        }
+        __syncthreads();
+
+        // ---------------------------------------------------------------- conv1: 3x3, stride 2, pad 1
+        f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+        {
+            const f32x4 *bp = (const f32x4 *)R.wp1 + (size_t)wave * (K1_CHUNKS + 1) * 128 + lane;
+            f32x4 b0 = bp[0], b1 = bp[64];
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+                // per-lane source pixel of both m-tiles for this tap
+                int pyc[2], pxc[2];
+                bool ok[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int p = 32 * t + l31;
+                    const int py = 2 * (p >> 3) + ky - 1, px = 2 * (p & 7) + kx - 1;
+                    ok[t] = (py >= 0) && (px >= 0);
+                    pyc[t] = max(py, 0);
+                    pxc[t] = max(px, 0);
+                }
+                float a0[4], a1[4];
+                // --- chunk 0: level 0 of both images; k = 2q+half -> (img0 c0,c1,c2, img1 c0,c1,c2, 0, 0)
+                {
+                    f32x4 nb0 = bp[128], nb1 = bp[192];
+                    bp += 128;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int pofs = pyc[t] * 16 + pxc[t];
+                        const float s0 = ok[t] ? scale[pofs] : 0.f;
+                        const float s1 = ok[t] ? scale[256 + pofs] : 0.f;
+                        const float *t0 = tiles + TILE_L0 + pofs;
+                        const float *t1 = tiles + TILE_IMG + TILE_L0 + pofs;
+                        float v0 = t0[half * 256] * s0;                                   // img0 c0 | c1
+                        float v1 = half ? t1[0] * s1 : t0[512] * s0;                      // img0 c2 | img1 c0
+                        float v2 = t1[(1 + half) * 256] * s1;                             // img1 c1 | c2
+                        if (t == 0) { a0[0] = v0; a0[1] = v1; a0[2] = v2; a0[3] = 0.f; }
+                        else        { a1[0] = v0; a1[1] = v1; a1[2] = v2; a1[3] = 0.f; }
+                    }
+                    P2P_CHUNK_MFMA(a0, a1)
+                    b0 = nb0; b1 = nb1;
+                }
+                // --- chunks 1..64: (img, level 1..3) segments, 8 channels per chunk
+                for (int img = 0; img < 2; ++img) {
+                    const float s0 = ok[0] ? scale[img * 256 + pyc[0] * 16 + pxc[0]] : 0.f;
+                    const float s1 = ok[1] ? scale[img * 256 + pyc[1] * 16 + pxc[1]] : 0.f;
+#pragma unroll
+                    for (int j = 1; j < 4; ++j) {
+                        const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
+                        const int CS = Rr * Rr;
+                        const int nchunk = (j == 3) ? 16 : 8;
+                        const int off = (j == 1) ? TILE_L1 : (j == 2) ? TILE_L2 : TILE_L3;
+                        const float *base = tiles + img * TILE_IMG + off + half * CS;
+                        const float *p0 = base + cell(y0[img], pyc[0], j, args.H[img]) * Rr +
+                                          cell(x0[img], pxc[0], j, args.W[img]);
+                        const float *p1 = base + cell(y0[img], pyc[1], j, args.H[img]) * Rr +
+                                          cell(x0[img], pxc[1], j, args.W[img]);
+                        for (int ch = 0; ch < nchunk; ++ch) {
+                            f32x4 nb0 = bp[128], nb1 = bp[192];
+                            bp += 128;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                a0[q] = p0[(ch * 8 + 2 * q) * CS] * s0;
+                                a1[q] = p1[(ch * 8 + 2 * q) * CS] * s1;
+                            }
+                            P2P_CHUNK_MFMA(a0, a1)
+                            b0 = nb0; b1 = nb1;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();   // all waves are done reading the patch tiles
+
+        // BN1 (folded scale/shift) and spill H[c][px] to LDS for conv2's A operand
+        {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n = wave * 64 + u * 32 + l31;
+                const float s = R.bn1s[n], b = R.bn1b[n];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const f32x16 &a = (t == 0) ? (u == 0 ? acc00 : acc01) : (u == 0 ? acc10 : acc11);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v;
+                        v[0] = fmaf(a[4 * g + 0], s, b);
+                        v[1] = fmaf(a[4 * g + 1], s, b);
+                        v[2] = fmaf(a[4 * g + 2], s, b);
+                        v[3] = fmaf(a[4 * g + 3], s, b);
+                        *(f32x4 *)(Hbuf + n * HSTRIDE + 32 * t + 8 * g + 4 * half) = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---------------------------------------------------------------- conv2: 3x3, stride 1, pad 1
+        acc00 = (f32x16){0}; acc01 = (f32x16){0}; acc10 = (f32x16){0}; acc11 = (f32x16){0};
+        {
+            const f32x4 *bp = (const f32x4 *)R.wp2 + (size_t)wave * (K2_CHUNKS + 1) * 128 + lane;
+            f32x4 b0 = bp[0], b1 = bp[64];
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const float *p0, *p1;
+                float m0, m1;
+                {
+                    const int oy = (l31 >> 3) + ky - 1, ox = (l31 & 7) + kx - 1;
+                    const bool okx = (ox >= 0) && (ox < 8);
+                    const bool ok0 = okx && (oy >= 0);                 // m-tile 0: rows 0..3 (+ky-1 <= 4)
+                    const bool ok1 = okx && (oy + 4 < 8);              // m-tile 1: rows 4..7 (+ky-1 >= 3)
+                    m0 = ok0 ? 1.f : 0.f;
+                    m1 = ok1 ? 1.f : 0.f;
+                    p0 = Hbuf + half * HSTRIDE + (ok0 ? oy * 8 + ox : 0);
+                    p1 = Hbuf + half * HSTRIDE + (ok1 ? (oy + 4) * 8 + ox : 0);
+                }
+                for (int ch = 0; ch < K2_CHUNKS_PER_TAP; ++ch) {
+                    f32x4 nb0 = bp[128], nb1 = bp[192];
+                    bp += 128;
+                    float a0[4], a1[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        a0[q] = p0[(ch * 8 + 2 * q) * HSTRIDE] * m0;
+                        a1[q] = p1[(ch * 8 + 2 * q) * HSTRIDE] * m1;
+                    }
+                    P2P_CHUNK_MFMA(a0, a1)
+                    b0 = nb0; b1 = nb1;
+                }
+            }
+        }
+
+        // BN2 -> ReLU -> max over the 8x8 outputs (BN before max: its scale may be negative)
+        {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n = wave * 64 + u * 32 + l31;
+                const float s = R.bn2s[n], b = R.bn2b[n];
+                const f32x16 &aa = (u == 0) ? acc00 : acc01;
+                const f32x16 &ab = (u == 0) ? acc10 : acc11;
+                float m = 0.f;                                  // ReLU folded into the max
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    m = fmaxf(m, fmaf(aa[r], s, b));
+                    m = fmaxf(m, fmaf(ab[r], s, b));
+                }
+                m = fmaxf(m, __shfl_xor(m, 32));
+                if (half == 0) V[n] = m;
+            }
+        }
+        __syncthreads();
+
+        // ---------------------------------------------------------------- FC tail (modules.py:89-99)
+        {
+            const f32x4 *w = (const f32x4 *)R.fc1t + tid;
+            float s = 0.f;
+#pragma unroll 8
+            for (int kq = 0; kq < 128; ++kq) {
+                f32x4 wv = w[kq * 512];
+                s = fmaf(wv[0], V[4 * kq + 0], s);
+                s = fmaf(wv[1], V[4 * kq + 1], s);
+                s = fmaf(wv[2], V[4 * kq + 2], s);
+                s = fmaf(wv[3], V[4 * kq + 3], s);
+            }
+            s += R.fc1b[tid];
+            F1[tid] = fmaxf(fmaf(s, R.bnf1s[tid], R.bnf1b[tid]), 0.f);
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const f32x4 *w = (const f32x4 *)R.fc2t + tid;
+            float s = 0.f;
+#pragma unroll 8
+            for (int kq = 0; kq < 128; ++kq) {
+                f32x4 wv = w[kq * 256];
+                s = fmaf(wv[0], F1[4 * kq + 0], s);
+                s = fmaf(wv[1], F1[4 * kq + 1], s);
+                s = fmaf(wv[2], F1[4 * kq + 2], s);
+                s = fmaf(wv[3], F1[4 * kq + 3], s);
+            }
+            s += R.fc2b[tid];
+            F2[tid] = fmaxf(fmaf(s, R.bnf2s[tid], R.bnf2b[tid]), 0.f);
+        }
+        __syncthreads();
+        if (tid < 5) {
+            const float *w = R.fc3 + tid * 256;
+            float s = 0.f;
+            for (int k = 0; k < 256; ++k) s = fmaf(w[k], F2[k], s);
+            s += R.fc3b[tid];
+            misc[tid] = s;
+            if (args.raw[lvl]) args.raw[lvl][(size_t)prop * 5 + tid] = s;
+            // parse_regressor_out (patch2pix.py:138-155), psize 16, ptype 'center'
+            if (tid < 4) {
+                const float off = 16.0f * tanhf(fmaxf(s, 0.f)) - 8.0f;
+                float fm = misc[8 + tid] + off;
+                const float hi = (float)((tid & 1) ? args.H[tid >> 1] : args.W[tid >> 1]);
+                fm = fminf(fmaxf(fm, 0.f), hi);
+                if (args.matches[lvl]) args.matches[lvl][(size_t)prop * 4 + tid] = fm;
+                misc[8 + tid] = fm;       // becomes the next level's proposal (un-truncated)
+            } else {
+                if (args.probs[lvl]) args.probs[lvl][prop] = 1.0f / (1.0f + expf(-s));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// host side: weight packing
+// --------------------------------------------------------------------------------------------------
+
+// channel (0..517) of the concatenated [im1 259 | im2 259] regressor input for conv1 K index r (0..519)
+// inside one tap; -1 for the two padding slots.
+static int conv1_channel_of(int r) {
+    if (r < 8) {
+        if (r >= 6) return -1;
+        return (r / 3) * 259 + (r % 3);
+    }
+    const int img = (r - 8) / 256, cc = (r - 8) % 256;
+    return img * 259 + 3 + cc;
+}
+
+static void fold_bn(const p2p_bn_params &bn, int n, float *scale, float *shift) {
+    for (int i = 0; i < n; ++i) {
+        const float inv = 1.0f / std::sqrt(bn.running_var[i] + 1e-5f);
+        const float a = bn.weight[i] * inv;
+        scale[i] = a;
+        shift[i] = bn.bias[i] - bn.running_mean[i] * a;
+    }
+}
+
+}  // namespace p2p
+
+using namespace p2p;
+
+extern "C" int p2p_regressor_create(const p2p_regressor_params *p, p2p_regressor **out) {
+    P2P_REQUIRE(p && out, P2P_EINVAL, "p2p_regressor_create: null argument");
+    const float *const need[] = {p->conv1_w, p->conv2_w, p->fc1_w, p->fc1_b, p->fc2_w, p->fc2_b, p->fc3_w, p->fc3_b,
+                                 p->bn1.weight, p->bn1.bias, p->bn1.running_mean, p->bn1.running_var,
+                                 p->bn2.weight, p->bn2.bias, p->bn2.running_mean, p->bn2.running_var,
+                                 p->bnf1.weight, p->bnf1.bias, p->bnf1.running_mean, p->bnf1.running_var,
+                                 p->bnf2.weight, p->bnf2.bias, p->bnf2.running_mean, p->bnf2.running_var};
+    for (const float *q : need) P2P_REQUIRE(q, P2P_EINVAL, "p2p_regressor_create: null weight pointer");
+
+    // layout of the single device allocation (floats)
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += (n + 63) & ~size_t(63); return o; };
+    const size_t o_wp1 = take(WP1_FLOATS), o_wp2 = take(WP2_FLOATS);
+    const size_t o_bn1s = take(512), o_bn1b = take(512), o_bn2s = take(512), o_bn2b = take(512);
+    const size_t o_fc1t = take(512 * 512), o_fc1b = take(512), o_bnf1s = take(512), o_bnf1b = take(512);
+    const size_t o_fc2t = take(256 * 512), o_fc2b = take(256), o_bnf2s = take(256), o_bnf2b = take(256);
+    const size_t o_fc3 = take(5 * 256), o_fc3b = take(8);
+    std::vector<float> h(off, 0.f);
+
+    // conv1: Wp1[w][kc][u][lane][q] = W1[n = 64w+32u+(lane&31)][channel(kidx)][tap],
+    //        kidx = 8*(kc % 65) + 2q + (lane>>5), tap = kc / 65
+    for (int w = 0; w < 8; ++w)
+        for (int kc = 0; kc < K1_CHUNKS; ++kc) {
+            const int tap = kc / K1_CHUNKS_PER_TAP, kin = kc % K1_CHUNKS_PER_TAP;
+            for (int u = 0; u < 2; ++u)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = 64 * w + 32 * u + (lane & 31);
+                        const int ch = conv1_channel_of(8 * kin + 2 * q + (lane >> 5));
+                        const size_t dst = o_wp1 + ((((size_t)w * (K1_CHUNKS + 1) + kc) * 2 + u) * 64 + lane) * 4 + q;
+                        h[dst] = (ch < 0) ? 0.f : p->conv1_w[((size_t)n * 518 + ch) * 9 + tap];
+                    }
+        }
+    // conv2: kidx = 8*(kc % 64) + 2q + (lane>>5) is the input channel, tap = kc / 64
+    for (int w = 0; w < 8; ++w)
+        for (int kc = 0; kc < K2_CHUNKS; ++kc) {
+            const int tap = kc / K2_CHUNKS_PER_TAP, kin = kc % K2_CHUNKS_PER_TAP;
+            for (int u = 0; u < 2; ++u)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = 64 * w + 32 * u + (lane & 31);
+                        const int ch = 8 * kin + 2 * q + (lane >> 5);
+                        const size_t dst = o_wp2 + ((((size_t)w * (K2_CHUNKS + 1) + kc) * 2 + u) * 64 + lane) * 4 + q;
+                        h[dst] = p->conv2_w[((size_t)n * 512 + ch) * 9 + tap];
+                    }
+        }
+    fold_bn(p->bn1, 512, &h[o_bn1s], &h[o_bn1b]);
+    fold_bn(p->bn2, 512, &h[o_bn2s], &h[o_bn2b]);
+    fold_bn(p->bnf1, 512, &h[o_bnf1s], &h[o_bnf1b]);
+    fold_bn(p->bnf2, 256, &h[o_bnf2s], &h[o_bnf2b]);
+    // fc weights as [k/4][out][4] so that a wave reads 1 KiB contiguous per step
+    for (int o = 0; o < 512; ++o)
+        for (int k = 0; k < 512; ++k) h[o_fc1t + ((size_t)(k / 4) * 512 + o) * 4 + (k & 3)] = p->fc1_w[(size_t)o * 512 + k];
+    for (int o = 0; o < 256; ++o)
+        for (int k = 0; k < 512; ++k) h[o_fc2t + ((size_t)(k / 4) * 256 + o) * 4 + (k & 3)] = p->fc2_w[(size_t)o * 512 + k];
+    for (int i = 0; i < 512; ++i) h[o_fc1b + i] = p->fc1_b[i];
+    for (int i = 0; i < 256; ++i) h[o_fc2b + i] = p->fc2_b[i];
+    for (int i = 0; i < 5 * 256; ++i) h[o_fc3 + i] = p->fc3_w[i];
+    for (int i = 0; i < 5; ++i) h[o_fc3b + i] = p->fc3_b[i];
+
+    float *dev = nullptr;
+    P2P_HIP_CHECK(hipMalloc(&dev, off * sizeof(float)));
+    hipError_t e = hipMemcpy(dev, h.data(), off * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(dev);
+        set_error("hipMemcpy of packed regressor weights failed: %s", hipGetErrorString(e));
+        return P2P_EHIP;
+    }
+    p2p_regressor *r = new p2p_regressor();
+    r->dev = dev;
+    r->wp1 = dev + o_wp1; r->wp2 = dev + o_wp2;
+    r->bn1s = dev + o_bn1s; r->bn1b = dev + o_bn1b; r->bn2s = dev + o_bn2s; r->bn2b = dev + o_bn2b;
+    r->fc1t = dev + o_fc1t; r->fc1b = dev + o_fc1b; r->bnf1s = dev + o_bnf1s; r->bnf1b = dev + o_bnf1b;
+    r->fc2t = dev + o_fc2t; r->fc2b = dev + o_fc2b; r->bnf2s = dev + o_bnf2s; r->bnf2b = dev + o_bnf2b;
+    r->fc3 = dev + o_fc3; r->fc3b = dev + o_fc3b;
+    *out = r;
+    return P2P_OK;
+}
+
+extern "C" void p2p_regressor_destroy(p2p_regressor *reg) {
+    if (!reg) return;
+    (void)hipFree(reg->dev);
+    delete reg;
+}
+
+static RegDev to_dev(const p2p_regressor *r) {
+    RegDev d;
+    d.wp1 = r->wp1; d.wp2 = r->wp2; d.bn1s = r->bn1s; d.bn1b = r->bn1b; d.bn2s = r->bn2s; d.bn2b = r->bn2b;
+    d.fc1t = r->fc1t; d.fc1b = r->fc1b; d.bnf1s = r->bnf1s; d.bnf1b = r->bnf1b;
+    d.fc2t = r->fc2t; d.fc2b = r->fc2b; d.bnf2s = r->bnf2s; d.bnf2b = r->bnf2b; d.fc3 = r->fc3; d.fc3b = r->fc3b;
+    return d;
+}
+
+extern "C" int p2p_regress(const p2p_regressor *reg1, const p2p_regressor *reg2,
+                           const p2p_pyramid *im1, const p2p_pyramid *im2,
+                           const void *proposals, int is_float, int n,
+                           float *matches1, float *probs1, float *raw1,
+                           float *matches2, float *probs2, float *raw2, p2p_stream_t stream) {
+    P2P_REQUIRE(reg1 && im1 && im2, P2P_EINVAL, "p2p_regress: null argument");
+    P2P_REQUIRE(n >= 0, P2P_EINVAL, "p2p_regress: negative proposal count");
+    if (n == 0) return P2P_OK;
+    P2P_REQUIRE(proposals, P2P_EINVAL, "p2p_regress: null proposals");
+    P2P_REQUIRE(reg2 ? (matches2 && probs2) : (matches1 && probs1), P2P_EINVAL, "p2p_regress: missing output buffers");
+    const p2p_pyramid *im[2] = {im1, im2};
+    RegressArgs a;
+    for (int i = 0; i < 2; ++i) {
+        P2P_REQUIRE(im[i]->height > 0 && im[i]->width > 0 && im[i]->height % 8 == 0 && im[i]->width % 8 == 0,
+                    P2P_EINVAL, "p2p_regress: image %d size %dx%d must be positive multiples of 8", i + 1,
+                    im[i]->height, im[i]->width);
+        for (int j = 0; j < 4; ++j) {
+            P2P_REQUIRE(im[i]->level[j], P2P_EINVAL, "p2p_regress: null pyramid level");
+            a.pyr[i][j] = im[i]->level[j];
+        }
+        a.H[i] = im[i]->height;
+        a.W[i] = im[i]->width;
+    }
+    a.proposals = proposals; a.is_float = is_float; a.n = n; a.nlevels = reg2 ? 2 : 1;
+    a.reg[0] = to_dev(reg1);
+    a.reg[1] = reg2 ? to_dev(reg2) : a.reg[0];
+    a.matches[0] = matches1; a.probs[0] = probs1; a.raw[0] = raw1;
+    a.matches[1] = matches2; a.probs[1] = probs2; a.raw[1] = raw2;
+
+    static bool attr_set = false;
+    if (!attr_set) {
+        P2P_HIP_CHECK(hipFuncSetAttribute((const void *)regress_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(regress_kernel, dim3(n), dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+    return check_launch("regress_kernel");
+}

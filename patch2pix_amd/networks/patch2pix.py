@@ -1,0 +1,296 @@
+"""`Patch2Pix` with the reference's public surface (networks/patch2pix.py) on top of libp2p_hip.
+
+Same constructor config, attributes (`device`, `upsample`, `psize`, `panc`, ...), method names,
+argument meaning and return layouts as the reference class, so callers such as
+utils/eval/model_helper.py (and image-matching-toolbox through it) work unchanged.  The ResNet
+backbone runs on PyTorch-ROCm; everything after the feature pyramid is HIP.  Inference only:
+`config.training=True` raises (training is out of scope).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import resnet
+from .utils import filter_coarse
+from .. import ops
+
+
+class _Holder(nn.Module):
+    """Parameter container that reproduces a sub-tree of the reference state_dict."""
+
+    def __init__(self, spec):
+        super().__init__()
+        children = {}
+        for name, (shape, kind) in spec.items():
+            head, _, rest = name.partition(".")
+            if rest:
+                children.setdefault(head, {})[rest] = (shape, kind)
+            elif kind == "param":
+                self.register_parameter(head, nn.Parameter(torch.zeros(shape), requires_grad=False))
+            else:
+                dtype = torch.int64 if kind == "long" else torch.float32
+                self.register_buffer(head, torch.zeros(shape, dtype=dtype))
+        for head, sub in children.items():
+            self.add_module(head, _Holder(sub))
+
+
+def _bn_spec(prefix, n):
+    return {f"{prefix}.weight": ((n,), "param"), f"{prefix}.bias": ((n,), "param"),
+            f"{prefix}.running_mean": ((n,), "buffer"), f"{prefix}.running_var": ((n,), "buffer"),
+            f"{prefix}.num_batches_tracked": ((), "long")}
+
+
+def _regressor_spec(feat_dim):
+    spec = {"conv.0.weight": ((512, 2 * feat_dim, 3, 3), "param"), "conv.2.weight": ((512, 512, 3, 3), "param"),
+            "fc.0.weight": ((512, 512), "param"), "fc.0.bias": ((512,), "param"),
+            "fc.3.weight": ((256, 512), "param"), "fc.3.bias": ((256,), "param"),
+            "fc.6.weight": ((5, 256), "param"), "fc.6.bias": ((5,), "param")}
+    for prefix, n in (("conv.1", 512), ("conv.3", 512), ("fc.1", 512), ("fc.4", 256)):
+        spec.update(_bn_spec(prefix, n))
+    return spec
+
+
+_NCN_SPEC = {"conv.0.weight": ((3, 16, 1, 3, 3, 3), "param"), "conv.0.bias": ((16,), "param"),
+             "conv.2.weight": ((3, 1, 16, 3, 3, 3), "param"), "conv.2.bias": ((1,), "param")}
+
+
+class Delta4d:
+    """The reference's `delta4d` tuple (max_i, max_j, max_k, max_l), each int64 [B,1,h1,w1,h2,w2]
+    (networks/modules.py:24-34), kept packed (one byte per cell) until somebody indexes it."""
+
+    def __init__(self, packed, ksize):
+        self.packed = packed            # list over batch of uint8 [h1,w1,h2,w2]
+        self.ksize = ksize
+        self._planes = None
+
+    def _materialise(self):
+        if self._planes is None:
+            per_item = [ops.delta_unpack(p, self.ksize) for p in self.packed]
+            self._planes = tuple(torch.stack([it[i] for it in per_item]).unsqueeze(1) for i in range(4))
+        return self._planes
+
+    def __iter__(self):
+        return iter(self._materialise())
+
+    def __len__(self):
+        return 4
+
+    def __getitem__(self, i):
+        return self._materialise()[i]
+
+
+class Patch2Pix(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.device = torch.device(config.device)
+        if self.device.type != "cuda":
+            raise RuntimeError("patch2pix_amd runs the matching path on an MI355X; no CPU fallback exists "
+                               f"(config.device={config.device})")
+        if getattr(config, "training", False):
+            raise NotImplementedError("training is out of scope of the MI355X matching path")
+        self.backbone = config.backbone
+        if self.backbone != "ResNet34":
+            raise NotImplementedError(f"backbone {self.backbone}: only ResNet34 (the released model) is provided")
+        self.change_stride = config.change_stride
+        self.upsample = 16
+        self.feats_downsample = [1, 2, 2, 2, 2]
+        feat_dims = [3, 64, 64, 128, 256]
+        self.extract = resnet.ResNet34()
+        if self.change_stride:
+            self.extract.change_stride(target="layer3")
+            self.upsample //= 2
+            self.feats_downsample[-1] = 1
+        else:
+            raise NotImplementedError("change_stride=False (upsample 16) is not implemented by the HIP fine stage")
+        self.ncn = _Holder(_NCN_SPEC)
+
+        self.regressor_config = config.regressor_config
+        self.regress_mid = None
+        self.regress_fine = None
+        if self.regressor_config:
+            rc = self.regressor_config
+            self.regr_batch = config.regr_batch
+            self.feat_idx = list(config.feat_idx)
+            if self.feat_idx != [0, 1, 2, 3]:
+                raise NotImplementedError(f"feat_idx {self.feat_idx}: only [0,1,2,3] is implemented")
+            rc.feat_dim = sum(feat_dims[i] for i in self.feat_idx)
+            if (list(rc.conv_dims), list(rc.conv_kers), list(getattr(rc, "conv_strs", [2, 2])), list(rc.fc_dims),
+                    rc.feat_comb) != ([512, 512], [3, 3], [2, 1], [512, 256], "pre"):
+                raise NotImplementedError("only the released regressor configuration is implemented")
+            self.ptype = ["center", "center"]
+            self.psize = rc.psize
+            if list(self.psize) != [16, 16]:
+                raise NotImplementedError("psize must be [16,16]")
+            self.pshift = rc.pshift
+            self.panc = rc.panc
+            self.shared = rc.shared
+            self.regress_mid = _Holder(_regressor_spec(rc.feat_dim))
+            self.regress_fine = self.regress_mid if self.shared else _Holder(_regressor_spec(rc.feat_dim))
+        self.to(self.device)
+        self._packed = None
+        self.init_weights_(weights_dict=config.weights_dict)
+        self.eval()
+
+    # ------------------------------------------------------------------ weights
+    def init_weights_(self, weights_dict=None, pretrained=True):
+        """Load a reference state_dict (networks/patch2pix.py:98-109).  `extract.layer4.*` and any other
+        key this inference-only model does not own is ignored, like the reference's strict=False branch."""
+        if weights_dict:
+            own = self.state_dict()
+            picked = {k: v for k, v in weights_dict.items() if k in own}
+            missing = [k for k in own if k not in picked and not k.endswith("num_batches_tracked")]
+            if missing and any(not k.startswith("extract.") for k in missing) and any(
+                    k.startswith(("ncn.", "regress_")) for k in weights_dict):
+                raise KeyError(f"checkpoint lacks hot-path weights: {missing[:5]} ...")
+            self.load_state_dict(picked, strict=False)
+        self._packed = None
+
+    def load_state_dict(self, *args, **kwargs):
+        self._packed = None
+        return super().load_state_dict(*args, **kwargs)
+
+    def _weights(self):
+        """Pack (BN folding, MFMA fragment order, transposed-branch filters) once per weight load."""
+        if self._packed is None:
+            sd = self.state_dict()
+            ncn = ops.NcnWeights(sd["ncn.conv.0.weight"], sd["ncn.conv.0.bias"], sd["ncn.conv.2.weight"],
+                                 sd["ncn.conv.2.bias"], self.device)
+            mid = fine = None
+            if self.regress_mid is not None:
+                sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+                mid = ops.RegressorWeights(sub("regress_mid."), self.device)
+                fine = mid if self.shared else ops.RegressorWeights(sub("regress_fine."), self.device)
+            self._packed = (ncn, mid, fine)
+        return self._packed
+
+    # ------------------------------------------------------------------ coarse stage
+    def forward_coarse_match(self, feat1, feat2, ksize=1):
+        ncn = self._weights()[0]
+        corr, packed = [], []
+        for b in range(feat1.shape[0]):
+            c, d = ops.coarse_forward(feat1[b], feat2[b], ksize, ncn)
+            corr.append(c)
+            packed.append(d)
+        corr4d = torch.stack(corr).unsqueeze(1)
+        delta4d = Delta4d(packed, ksize) if ksize > 1 else None
+        return corr4d, delta4d
+
+    def forward(self, im1, im2, ksize=1, return_feats=False):
+        if return_feats:
+            feat1s = self.extract.pyramid(im1)
+            feat2s = self.extract.pyramid(im2)
+            feat1, feat2 = feat1s[-1], feat2s[-1]
+        else:
+            feat1 = self.extract(im1, early_feat=True)
+            feat2 = self.extract(im2, early_feat=True)
+        corr4d, delta4d = self.forward_coarse_match(feat1, feat2, ksize=ksize)
+        if return_feats:
+            return corr4d, delta4d, feat1s, feat2s
+        return corr4d, delta4d
+
+    def cal_coarse_matches(self, corr4d, delta4d, ksize=1, do_softmax=True, upsample=16, sort=False,
+                           center=True, pshift=0):
+        if not do_softmax:
+            raise NotImplementedError("cal_coarse_matches(do_softmax=False) is not implemented")
+        if delta4d is not None and not isinstance(delta4d, Delta4d):
+            di, dj, dk, dl = delta4d            # reference-format int64 planes -> packed byte
+            s = ((di * ksize + dj) * ksize + dk) * ksize + dl
+            delta4d = Delta4d([p[0].to(torch.uint8).contiguous() for p in s], ksize)
+        matches, scores = [], []
+        for b in range(corr4d.shape[0]):
+            m, s = ops.coarse_matches(corr4d[b, 0], delta4d.packed[b] if delta4d is not None else None,
+                                      ksize, upsample, center)
+            matches.append(m)
+            scores.append(s)
+        matches_, score_ = torch.stack(matches), torch.stack(scores)
+        if sort:
+            order = torch.sort(-score_)[1]
+            score_ = torch.gather(score_, 1, order)
+            matches_ = torch.gather(matches_, 1, order.unsqueeze(-1).expand(-1, -1, 4))
+        return matches_, score_
+
+    def shift_to_anchors(self, matches):
+        """patch2pix.py:377-402: panc == 8 replaces each match by its 8 corner-shifted anchors."""
+        if self.panc == 1:
+            return matches
+        s = self.pshift
+        tmpl = torch.tensor([[-s, -s, 0, 0], [s, -s, 0, 0], [-s, s, 0, 0], [s, s, 0, 0],
+                             [0, 0, -s, -s], [0, 0, s, -s], [0, 0, -s, s], [0, 0, s, s]], device=self.device)
+        return [(m.unsqueeze(1) + tmpl).reshape(-1, 4) for m in matches]
+
+    # ------------------------------------------------------------------ fine stage
+    def forward_fine_match(self, feats1, feats2, coarse_matches, psize=16, ptype="center", regressor=None):
+        """One regressor over every batch item (reference patch2pix.py:186-218).  `regressor` is
+        `self.regress_mid` / `self.regress_fine` like in the reference call sites."""
+        _, mid_w, fine_w = self._weights()
+        w = fine_w if (regressor is self.regress_fine and regressor is not self.regress_mid) else mid_w
+        fine_matches, masks = [], []
+        for b, props in enumerate(coarse_matches):
+            props = self._as_proposals(props)
+            out = ops.regress(w, None, [f[b] for f in feats1[:4]], [f[b] for f in feats2[:4]], props)
+            fine_matches.append(out["matches1"])
+            masks.append(out["probs1"])
+        return fine_matches, masks
+
+    def _as_proposals(self, props):
+        props = props.to(self.device)
+        if props.dtype not in (torch.int64, torch.float32):
+            props = props.float() if props.is_floating_point() else props.long()
+        return props
+
+    def _fine_chain(self, feats1, feats2, coarse_matches):
+        """mid -> fine for every batch item in one launch each (patch2pix.py:259-272)."""
+        _, mid_w, fine_w = self._weights()
+        mids, mid_scores, fines, fine_scores = [], [], [], []
+        for b, props in enumerate(coarse_matches):
+            out = ops.regress(mid_w, fine_w, [f[b] for f in feats1[:4]], [f[b] for f in feats2[:4]],
+                              self._as_proposals(props))
+            mids.append(out["matches1"]); mid_scores.append(out["probs1"])
+            fines.append(out["matches2"]); fine_scores.append(out["probs2"])
+        return fines, fine_scores, mids, mid_scores
+
+    # ------------------------------------------------------------------ public prediction API
+    def predict_coarse(self, im1, im2, ksize=2, ncn_thres=0.0, mutual=False, center=True):
+        corr4d, delta4d = self.forward(im1, im2, ksize)
+        coarse_matches, match_scores = self.cal_coarse_matches(corr4d, delta4d, ksize=ksize,
+                                                               upsample=self.upsample, center=center)
+        return filter_coarse(coarse_matches, match_scores, ncn_thres, mutual)
+
+    def predict_fine_from_feats(self, feats1, feats2, ksize=2, ncn_thres=0.0, mutual=True, return_all=False,
+                                ptmax=None):
+        """predict_fine after the backbone: the part of the path that is HIP end to end.
+        `ptmax` (opt-in, training semantics of utils.py:55-63) caps/tiles the proposals."""
+        corr4d, delta4d = self.forward_coarse_match(feats1[-1], feats2[-1], ksize=ksize)
+        coarse_matches, match_scores = self.cal_coarse_matches(corr4d, delta4d, ksize=ksize,
+                                                               upsample=self.upsample, center=True)
+        coarse_matches, match_scores = filter_coarse(coarse_matches, match_scores, ncn_thres, mutual, ptmax=ptmax)
+        coarse_matches = self.shift_to_anchors(coarse_matches)
+        fine, fine_scores, mid, mid_scores = self._fine_chain(feats1, feats2, coarse_matches)
+        if return_all:
+            return fine, fine_scores, mid, mid_scores, coarse_matches
+        return fine, fine_scores, coarse_matches
+
+    def predict_fine(self, im1, im2, ksize=2, ncn_thres=0.0, mutual=True, return_all=False):
+        feats1 = self.extract.pyramid(im1)
+        feats2 = self.extract.pyramid(im2)
+        return self.predict_fine_from_feats(feats1, feats2, ksize, ncn_thres, mutual, return_all)
+
+    def refine_matches(self, im1, im2, coarse_matches, io_thres):
+        """patch2pix.py:278-318: refine caller-supplied coarse matches (numpy or tensor [N,4])."""
+        if len(coarse_matches) == 0:
+            return np.empty((0, 4)), np.empty((0,)), np.empty((0, 4))
+        if isinstance(coarse_matches, np.ndarray):
+            coarse_t = torch.from_numpy(coarse_matches).to(self.device)
+        else:
+            coarse_t = coarse_matches.to(self.device)
+            coarse_matches = coarse_matches.cpu().data.numpy()
+        feats1 = self.extract.pyramid(im1)
+        feats2 = self.extract.pyramid(im2)
+        fine, fine_scores, _, _ = self._fine_chain(feats1, feats2, [coarse_t])
+        refined = fine[0].cpu().data.numpy()
+        scores = fine_scores[0].cpu().data.numpy()
+        if io_thres > 0:
+            pos = np.where(scores > io_thres)[0]
+            if len(pos) > 0:
+                coarse_matches, refined, scores = coarse_matches[pos], refined[pos], scores[pos]
+        return refined, scores, coarse_matches

@@ -1,0 +1,190 @@
+"""Torch-tensor front end of the C ABI: owns nothing but the two kinds of weight handle.
+Every function launches asynchronously on torch's current HIP stream of the tensors' device."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise TypeError(f"{name} must be a float32 tensor on the GPU (got {t.dtype}, {t.device})")
+    return t.contiguous()
+
+
+def _host(t):
+    return t.detach().to("cpu", torch.float32).contiguous()
+
+
+class NcnWeights:
+    """Device-resident NeighConsensus filters (reference networks/ncn/model.py:124-143)."""
+
+    def __init__(self, w1, b1, w2, b2, device):
+        keep = [_host(w1), _host(b1), _host(w2), _host(b2)]
+        if tuple(keep[0].shape) != (3, 16, 1, 3, 3, 3) or tuple(keep[2].shape) != (3, 1, 16, 3, 3, 3):
+            raise NotImplementedError("only NeighConsensus(kernel_sizes=[3,3], channels=[16,1]) is implemented")
+        self.handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.p2p_ncn_create(*[t.data_ptr() for t in keep], ctypes.byref(self.handle)), "p2p_ncn_create")
+        self.device = torch.device(device)
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            _lib.p2p_ncn_destroy(self.handle)
+            self.handle = None
+
+
+class RegressorWeights:
+    """Device-resident packed FeatRegressNet (reference networks/modules.py:56-112).
+    `sd` maps the sub-state_dict keys ('conv.0.weight', 'fc.6.bias', ...) to tensors."""
+
+    def __init__(self, sd, device):
+        exp = {"conv.0.weight": (512, 518, 3, 3), "conv.2.weight": (512, 512, 3, 3), "fc.0.weight": (512, 512),
+               "fc.3.weight": (256, 512), "fc.6.weight": (5, 256)}
+        for k, shp in exp.items():
+            if tuple(sd[k].shape) != shp:
+                raise NotImplementedError(f"regressor {k} has shape {tuple(sd[k].shape)}; only the released "
+                                          f"configuration {shp} is implemented")
+        keep = {k: _host(v) for k, v in sd.items() if v.is_floating_point()}
+        p = _lib.RegressorParams()
+
+        def bn(prefix):
+            return _lib.BnParams(keep[prefix + ".weight"].data_ptr(), keep[prefix + ".bias"].data_ptr(),
+                                 keep[prefix + ".running_mean"].data_ptr(), keep[prefix + ".running_var"].data_ptr())
+
+        p.conv1_w = keep["conv.0.weight"].data_ptr(); p.bn1 = bn("conv.1")
+        p.conv2_w = keep["conv.2.weight"].data_ptr(); p.bn2 = bn("conv.3")
+        p.fc1_w = keep["fc.0.weight"].data_ptr(); p.fc1_b = keep["fc.0.bias"].data_ptr(); p.bnf1 = bn("fc.1")
+        p.fc2_w = keep["fc.3.weight"].data_ptr(); p.fc2_b = keep["fc.3.bias"].data_ptr(); p.bnf2 = bn("fc.4")
+        p.fc3_w = keep["fc.6.weight"].data_ptr(); p.fc3_b = keep["fc.6.bias"].data_ptr()
+        self.handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.p2p_regressor_create(ctypes.byref(p), ctypes.byref(self.handle)), "p2p_regressor_create")
+        self.device = torch.device(device)
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            _lib.p2p_regressor_destroy(self.handle)
+            self.handle = None
+
+
+_workspaces = {}
+
+
+def _workspace(device, nbytes):
+    """One growing scratch buffer per (device, stream)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def coarse_forward(feat_a, feat_b, ksize, ncn, want_delta=True):
+    """forward_coarse_match for one pair.  feat_*: [C,h,w] fp32 GPU.  Returns (corr [hA',wA',hB',wB'],
+    packed delta uint8 of the same shape or None)."""
+    feat_a, feat_b = _f32c(feat_a, "feat_a"), _f32c(feat_b, "feat_b")
+    c, ha, wa = feat_a.shape
+    c2, hb, wb = feat_b.shape
+    if c != c2:
+        raise ValueError("channel mismatch between the two feature maps")
+    dev = feat_a.device
+    with torch.cuda.device(dev):
+        nbytes = _lib.p2p_coarse_workspace_bytes(c, ha, wa, hb, wb, ksize)
+        ws = _workspace(dev, max(nbytes, 256))
+        k = max(ksize, 1)
+        shape = (ha // k, wa // k, hb // k, wb // k)
+        corr = torch.empty(shape, dtype=torch.float32, device=dev)
+        delta = torch.empty(shape, dtype=torch.uint8, device=dev) if (ksize > 1 and want_delta) else None
+        _lib.check(_lib.p2p_coarse_forward(feat_a.data_ptr(), feat_b.data_ptr(), c, ha, wa, hb, wb, ksize, ncn.handle,
+                                           corr.data_ptr(), delta.data_ptr() if delta is not None else None,
+                                           ws.data_ptr(), ws.numel(), _stream()), "p2p_coarse_forward")
+    return corr, delta
+
+
+def delta_unpack(delta, ksize):
+    """Packed argmax byte -> the reference's (max_i, max_j, max_k, max_l) int64 tensors."""
+    out = torch.empty((4,) + tuple(delta.shape), dtype=torch.int64, device=delta.device)
+    with torch.cuda.device(delta.device):
+        _lib.check(_lib.p2p_delta_unpack(delta.data_ptr(), delta.numel(), ksize, out.data_ptr(), _stream()),
+                   "p2p_delta_unpack")
+    return out[0], out[1], out[2], out[3]
+
+
+def coarse_matches(corr, delta, ksize, upsample, center=True):
+    """cal_coarse_matches for one pair: ([nB+nA,4] int64 pixel matches, [nB+nA] fp32 scores)."""
+    corr = _f32c(corr, "corr4d")
+    ha, wa, hb, wb = corr.shape
+    n = ha * wa + hb * wb
+    dev = corr.device
+    matches = torch.empty((n, 4), dtype=torch.int64, device=dev)
+    scores = torch.empty((n,), dtype=torch.float32, device=dev)
+    if delta is not None:
+        delta = delta.contiguous()
+    with torch.cuda.device(dev):
+        _lib.check(_lib.p2p_coarse_matches(corr.data_ptr(), delta.data_ptr() if delta is not None else None,
+                                           ha, wa, hb, wb, ksize, upsample, int(bool(center)),
+                                           matches.data_ptr(), scores.data_ptr(), _stream()), "p2p_coarse_matches")
+    return matches, scores
+
+
+def _pyramid(levels):
+    if len(levels) != 4:
+        raise ValueError("a pyramid is the 4 maps of feat_idx [0,1,2,3]")
+    lv = [_f32c(t, "pyramid level") for t in levels]
+    h, w = lv[0].shape[-2:]
+    exp = [(3, h, w), (64, h // 2, w // 2), (64, h // 4, w // 4), (128, h // 8, w // 8)]
+    for t, e in zip(lv, exp):
+        if tuple(t.shape) != e:
+            raise ValueError(f"pyramid level has shape {tuple(t.shape)}, expected {e}")
+    p = _lib.Pyramid()
+    for j in range(4):
+        p.level[j] = lv[j].data_ptr()
+    p.height, p.width = h, w
+    return p, lv
+
+
+def regress(reg1, reg2, pyr1, pyr2, proposals, want_mid=True, want_raw=False):
+    """forward_fine_match for one pair; with reg2 the mid->fine chain runs in the same launch.
+
+    proposals: [n,4] int64 or float32 on the GPU.  Returns a dict with 'matches1','probs1'
+    (and 'matches2','probs2' when reg2 is given; 'raw*' on request)."""
+    dev = proposals.device
+    if proposals.dtype == torch.int64:
+        is_float = 0
+    elif proposals.dtype == torch.float32:
+        is_float = 1
+    else:
+        raise TypeError("proposals must be int64 or float32")
+    proposals = proposals.contiguous()
+    n = proposals.shape[0]
+    p1, keep1 = _pyramid(pyr1)
+    p2, keep2 = _pyramid(pyr2)
+    out = {}
+
+    def buf(key, cols, cond=True):
+        if not cond:
+            return None
+        out[key] = torch.empty((n, cols) if cols > 1 else (n,), dtype=torch.float32, device=dev)
+        return out[key].data_ptr()
+
+    two = reg2 is not None
+    m1 = buf("matches1", 4, want_mid or not two)
+    q1 = buf("probs1", 1, want_mid or not two)
+    r1 = buf("raw1", 5, want_raw)
+    m2 = buf("matches2", 4, two)
+    q2 = buf("probs2", 1, two)
+    r2 = buf("raw2", 5, two and want_raw)
+    if n:
+        with torch.cuda.device(dev):
+            _lib.check(_lib.p2p_regress(reg1.handle, reg2.handle if two else None, ctypes.byref(p1), ctypes.byref(p2),
+                                        proposals.data_ptr(), is_float, n, m1, q1, r1, m2, q2, r2, _stream()),
+                       "p2p_regress")
+    del keep1, keep2
+    return out
