@@ -145,7 +145,7 @@ __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
             const float *t = tiles + img * TILE_IMG;
             float ss = 0.f;
             {
-                const float *p = t + TILE_L0 + py * 16 + px;
+                const float *p = t + TILE_L0 + cell(y0[img], py, 0, args.H[img]) * 16 + cell(x0[img], px, 0, args.W[img]);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { float v = p[c * 256]; ss = fmaf(v, v, ss); }
             }
@@ -189,8 +189,10 @@ __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
                         const int pofs = pyc[t] * 16 + pxc[t];
                         const float s0 = ok[t] ? scale[pofs] : 0.f;
                         const float s1 = ok[t] ? scale[256 + pofs] : 0.f;
-                        const float *t0 = tiles + TILE_L0 + pofs;
-                        const float *t1 = tiles + TILE_IMG + TILE_L0 + pofs;
+                        const float *t0 = tiles + TILE_L0 + cell(y0[0], pyc[t], 0, args.H[0]) * 16 +
+                                          cell(x0[0], pxc[t], 0, args.W[0]);
+                        const float *t1 = tiles + TILE_IMG + TILE_L0 + cell(y0[1], pyc[t], 0, args.H[1]) * 16 +
+                                          cell(x0[1], pxc[t], 0, args.W[1]);
                         float v0 = t0[half * 256] * s0;                                   // img0 c0 | c1
                         float v1 = half ? t1[0] * s1 : t0[512] * s0;                      // img0 c2 | img1 c0
                         float v2 = t1[(1 + half) * 256] * s1;                             // img1 c1 | c2
