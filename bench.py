@@ -1,0 +1,161 @@
+#!/usr/bin/env python
+"""Throughput of the Patch2Pix matching hot path on MI355X (BASELINE.json metric: image-pairs/sec,
+480x640, ptmax=400).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of the hot path over one image pair whose feature pyramids are already resident in
+HBM: coarse stage (normalise, 4-D correlation + pool, mutual matching, consensus, matches) ->
+filter_coarse(ptmax=400) -> mid + fine regressors -> match arrays on the device.  Pairs are
+independent, so with N ranks every rank runs its own K pairs (weak scaling) and the match arrays are
+gathered once over RCCL inside the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, PTMAX, KSIZE = 480, 640, 400, 2
+# algorithmic work of one regress launch: per proposal per level
+#   conv1 2*64*512*(518*9) + conv2 2*64*512*(512*9) + fc 2*(512*512+512*256+256*5) flop
+FLOP_PER_PROPOSAL_LEVEL = 2 * 64 * 512 * (518 * 9) + 2 * 64 * 512 * (512 * 9) + 2 * (512 * 512 + 512 * 256 + 256 * 5)
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(ckpt, pyr1, pyr2):
+    """The CPU oracle (a port of the reference algorithm, oracle/p2p_oracle.py) on the host cores,
+    on a bounded sample of the same workload: the whole coarse stage of one 480x640 pair plus the
+    two regressors on 48 of the 400 proposals, extrapolated linearly in the proposal count."""
+    from oracle import p2p_oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = ckpt["state_dict"]
+    ncn, mid_p, fine_p = orc.split_params(sd)
+    sample = 48
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        corr, delta = orc.coarse_forward(pyr1[4], pyr2[4], KSIZE, ncn)
+        m, s = orc.cal_coarse_matches(corr, delta, KSIZE, 8)
+        cm, _ = orc.filter_coarse(m, s, 0.0, True, ptmax=PTMAX, rng=np.random.RandomState(0))
+        t1 = time.perf_counter()
+        mid, _, _ = orc.fine_level(pyr1[:4], pyr2[:4], cm[:sample], mid_p)
+        orc.fine_level(pyr1[:4], pyr2[:4], mid, fine_p)
+        t2 = time.perf_counter()
+    t_pair = (t1 - t0) + (t2 - t1) * (PTMAX / sample)
+    return {"value": 1.0 / t_pair, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"1 pair 480x640: full coarse stage ({t1 - t0:.2f} s) + both regressors on {sample}/400 "
+                      f"proposals ({t2 - t1:.2f} s, scaled x{PTMAX / sample:.2f}); torch-CPU fp32, {cores} threads"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from patch2pix_amd import ops
+    from patch2pix_amd.utils import synthetic
+    from patch2pix_amd.utils.eval import model_helper
+
+    ckpt = synthetic.make_checkpoint(0)
+    net = model_helper.load_model(ckpt, lprint=lambda *a: None)
+    # a few distinct synthetic pairs per rank, resident in HBM before the clock starts
+    npairs = 4
+    cpu_pairs = [synthetic.make_correlated_pyramids(1000 + rank * 16 + i, H, W) for i in range(npairs)]
+    pairs = [([t[None].to(dev) for t in p1], [t[None].to(dev) for t in p2]) for p1, p2 in cpu_pairs]
+    np.random.seed(1234 + rank)
+
+    def step(i):
+        f1, f2 = pairs[i % npairs]
+        return net.predict_fine_from_feats(f1, f2, ksize=KSIZE, ncn_thres=0.0, mutual=True, ptmax=PTMAX)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            step(i)
+        barrier()
+        ops.regress_events = []
+        t0 = time.perf_counter()
+        results = [step(i) for i in range(args.steps)]
+        # final gather of the match arrays (the only inter-GPU exchange of the path)
+        fine = torch.cat([r[0][0] for r in results])
+        score = torch.cat([r[1][0] for r in results])
+        if dist is not None:
+            rows = torch.tensor([fine.shape[0]], device=dev)
+            counts = [torch.zeros_like(rows) for _ in range(world)]
+            dist.all_gather(counts, rows)
+            cap = int(max(c.item() for c in counts))
+            payload = torch.zeros((cap, 5), device=dev)
+            payload[:fine.shape[0], :4] = fine
+            payload[:fine.shape[0], 4] = score
+            gathered = [torch.empty_like(payload) for _ in range(world)]
+            dist.all_gather(gathered, payload)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    events = ops.regress_events
+    ops.regress_events = None
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    kern_ms = [a.elapsed_time(b) for a, b, _, _ in events]
+    flop = sum(n * lv * FLOP_PER_PROPOSAL_LEVEL for _, _, n, lv in events) / max(len(events), 1)
+    avg_ms = sum(kern_ms) / max(len(kern_ms), 1)
+    achieved = flop / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+
+    if rank == 0:
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "regress_traffic.json")
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "image-pairs/sec (480x640, ptmax=400), matching hot path, feature pyramids resident in HBM",
+            "value": world * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "single 480x640 pair per step, ksize=2, ptmax=400 proposals, panc=1, "
+                                   "coarse (NCNet 4D) + mid/fine regressors; configs[1] of BASELINE.json",
+                       "pairs_per_step": 1, "parallelism": f"pairs sharded over {world} GPU(s), one final RCCL all_gather"},
+            "roofline": {"kernel": "regress_kernel", "bound": "mfma", "achieved": achieved,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": traffic, "avg_launch_ms": avg_ms, "flop_per_launch": flop},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ckpt, *cpu_pairs[0])
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

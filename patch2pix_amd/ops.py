@@ -75,6 +75,10 @@ class RegressorWeights:
 
 _workspaces = {}
 
+# Optional launch timing (bench.py): when a list is installed here, regress() brackets its launch
+# with HIP events recorded on the stream the kernel is launched on and appends (start, end, n).
+regress_events = None
+
 
 def _workspace(device, nbytes):
     """One growing scratch buffer per (device, stream)."""
@@ -183,8 +187,15 @@ def regress(reg1, reg2, pyr1, pyr2, proposals, want_mid=True, want_raw=False):
     r2 = buf("raw2", 5, two and want_raw)
     if n:
         with torch.cuda.device(dev):
+            ev = None
+            if regress_events is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             _lib.check(_lib.p2p_regress(reg1.handle, reg2.handle if two else None, ctypes.byref(p1), ctypes.byref(p2),
                                         proposals.data_ptr(), is_float, n, m1, q1, r1, m2, q2, r2, _stream()),
                        "p2p_regress")
+            if ev is not None:
+                ev[1].record()
+                regress_events.append((ev[0], ev[1], n, 2 if two else 1))
     del keep1, keep2
     return out
