@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs-per-step", type=int, default=5,
+                    help="image pairs per step; their proposals share one regress launch (fills the 256 CUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -84,14 +86,21 @@ def main():
 
     ckpt = synthetic.make_checkpoint(0)
     net = model_helper.load_model(ckpt, lprint=lambda *a: None)
-    # a few distinct synthetic pairs per rank, resident in HBM before the clock starts
-    npairs = 4
-    cpu_pairs = [synthetic.make_correlated_pyramids(1000 + rank * 16 + i, H, W) for i in range(npairs)]
-    pairs = [([t[None].to(dev) for t in p1], [t[None].to(dev) for t in p2]) for p1, p2 in cpu_pairs]
+    # a few distinct synthetic batches per rank, resident in HBM before the clock starts
+    B = args.pairs_per_step
+    nbatches = 2
+    cpu_pairs = [synthetic.make_correlated_pyramids(1000 + rank * 64 + i, H, W) for i in range(nbatches * B)]
+    batches = []
+    for k in range(nbatches):
+        chunk = cpu_pairs[k * B:(k + 1) * B]
+        f1 = [torch.stack([p[0][j] for p in chunk]).to(dev) for j in range(5)]
+        f2 = [torch.stack([p[1][j] for p in chunk]).to(dev) for j in range(5)]
+        batches.append((f1, f2))
     np.random.seed(1234 + rank)
+    from patch2pix_amd.gather import gather_matches
 
     def step(i):
-        f1, f2 = pairs[i % npairs]
+        f1, f2 = batches[i % nbatches]
         return net.predict_fine_from_feats(f1, f2, ksize=KSIZE, ncn_thres=0.0, mutual=True, ptmax=PTMAX)
 
     def barrier():
@@ -107,20 +116,15 @@ def main():
         t0 = time.perf_counter()
         results = [step(i) for i in range(args.steps)]
         # final gather of the match arrays (the only inter-GPU exchange of the path)
-        fine = torch.cat([r[0][0] for r in results])
-        score = torch.cat([r[1][0] for r in results])
-        if dist is not None:
-            rows = torch.tensor([fine.shape[0]], device=dev)
-            counts = [torch.zeros_like(rows) for _ in range(world)]
-            dist.all_gather(counts, rows)
-            cap = int(max(c.item() for c in counts))
-            payload = torch.zeros((cap, 5), device=dev)
-            payload[:fine.shape[0], :4] = fine
-            payload[:fine.shape[0], 4] = score
-            gathered = [torch.empty_like(payload) for _ in range(world)]
-            dist.all_gather(gathered, payload)
+        rows, ids = [], []
+        for i, (fine, score, coarse) in enumerate(results):
+            for b in range(B):
+                rows.append(torch.cat([fine[b], score[b][:, None], coarse[b].float()], dim=1))
+                ids.append(torch.full((fine[b].shape[0],), (i * world + rank) * B + b, dtype=torch.int64, device=dev))
+        all_rows, all_ids = gather_matches(torch.cat(rows), torch.cat(ids))
         barrier()
         elapsed = time.perf_counter() - t0
+    assert all_rows.shape[0] == world * args.steps * B * PTMAX
     events = ops.regress_events
     ops.regress_events = None
     if dist is not None:
@@ -140,12 +144,12 @@ def main():
             traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
         out = {
             "metric": "image-pairs/sec (480x640, ptmax=400), matching hot path, feature pyramids resident in HBM",
-            "value": world * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "value": world * args.steps * B / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "single 480x640 pair per step, ksize=2, ptmax=400 proposals, panc=1, "
-                                   "coarse (NCNet 4D) + mid/fine regressors; configs[1] of BASELINE.json",
-                       "pairs_per_step": 1, "parallelism": f"pairs sharded over {world} GPU(s), one final RCCL all_gather"},
+            "config": {"workload": "480x640 pairs, ksize=2, ptmax=400 proposals per pair, panc=1, coarse (NCNet 4D) + "
+                                   "mid/fine regressors; configs[1] of BASELINE.json, several pairs per step",
+                       "pairs_per_step": B, "parallelism": f"pairs sharded over {world} GPU(s), one final RCCL all_gather"},
             "roofline": {"kernel": "regress_kernel", "bound": "mfma", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                          "traffic": traffic, "avg_launch_ms": avg_ms, "flop_per_launch": flop},

@@ -124,6 +124,16 @@ int p2p_regress(const p2p_regressor *reg1, const p2p_regressor *reg2,
                 float *matches1, float *probs1, float *raw1,
                 float *matches2, float *probs2, float *raw2, p2p_stream_t stream);
 
+/* The same for `nitems` image pairs in one launch (the reference loops over the batch items of its
+ * list arguments, patch2pix.py:192): im1/im2 are arrays of nitems pyramids, counts[i] (HOST array) the
+ * number of proposals of item i; proposals and every output are the per-item arrays concatenated in
+ * item order.  Filling the chip matters here: one proposal occupies one compute unit.            */
+int p2p_regress_batch(const p2p_regressor *reg1, const p2p_regressor *reg2, int nitems,
+                      const p2p_pyramid *im1, const p2p_pyramid *im2, const int *counts,
+                      const void *proposals, int is_float,
+                      float *matches1, float *probs1, float *raw1,
+                      float *matches2, float *probs2, float *raw2, p2p_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -272,50 +272,110 @@ __global__ __launch_bounds__(256) void nc_layer1_kernel(const float *__restrict_
 }
 
 // layer 2: Y = relu(b2 + sum_{c<16} W2*H1[c]) + relu(b2 + sum_{c<16} W2^T*H1[16+c])
-constexpr int L2_CG = 8;     // channels staged in LDS per pass
-__global__ __launch_bounds__(256) void nc_layer2_kernel(const float *__restrict__ H1, Vol v,
+//
+// Work-group tile: 1 x tb x tc x (8*tdr) outputs; a thread owns a run of 8 consecutive outputs along
+// the last axis, so every 10-float LDS row read feeds 24 FMAs.  One hidden channel at a time is
+// staged (3 x (tb+2) x (tc+2) rows with halo, row stride 8*tdr+4 floats so that ds_read_b128 stays
+// 16-B aligned); at ~44 KB per work-group three of them share a CU and overlap each other's loads.
+struct NcTile { int tb, tc, tdr, rs; };
+
+__global__ __launch_bounds__(256) void nc_layer2_kernel(const float *__restrict__ H1, Vol v, NcTile t,
                                                         const float *__restrict__ w2cat, float b2,
                                                         float *__restrict__ Y) {
-    __shared__ float tile[L2_CG * HALO];
-    int a, b0, c0, d0;
-    tile_origin(v, a, b0, c0, d0);
-    const int tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float tile2[];      // [3][tb+2][tc+2][rs]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int td = 8 * t.tdr;
+    const int nd = (v.d3 + td - 1) / td, nc = (v.d2 + t.tc - 1) / t.tc, nb = (v.d1 + t.tb - 1) / t.tb;
+    int g = blockIdx.x;
+    const int d0 = (g % nd) * td; g /= nd;
+    const int c0 = (g % nc) * t.tc; g /= nc;
+    const int b0 = (g % nb) * t.tb; g /= nb;
+    const int a = g;
     const int nB = v.d2 * v.d3;
     const size_t nAB = (size_t)v.d0 * v.d1 * nB;
-    const int tb = tid >> 6, tc = (tid >> 3) & 7, td = tid & 7;
-    float out = 0.f;
-    for (int branch = 0; branch < 2; ++branch) {
-        float acc = 0.f;
-        for (int cg = 0; cg < 16; cg += L2_CG) {
-            const int cbase = branch * 16 + cg;
-            __syncthreads();
-            for (int e = tid; e < HALO; e += 256) {
-                int t = e;
-                const int dd = t % HD_; t /= HD_;
-                const int dc = t % HC_; t /= HC_;
-                const int db = t % HB_; t /= HB_;
-                const int ia = a + t - 1, ib = b0 + db - 1, ic = c0 + dc - 1, id = d0 + dd - 1;
-                const bool ok = ia >= 0 && ia < v.d0 && ib >= 0 && ib < v.d1 && ic >= 0 && ic < v.d2 && id >= 0 && id < v.d3;
-                const size_t pos = ok ? (size_t)(ia * v.d1 + ib) * nB + ic * v.d3 + id : 0;
+    const int hb = t.tb + 2, hc = t.tc + 2, ncol = td + 2;
+    const int nrows = 3 * hb * hc;
+    // this thread's run of 8 outputs
+    const int rr = tid % t.tdr, rc = (tid / t.tdr) % t.tc, rb = tid / (t.tdr * t.tc);
+    const bool active = rb < t.tb;
+    float out[8];
 #pragma unroll
-                for (int c = 0; c < L2_CG; ++c) tile[c * HALO + e] = ok ? H1[(cbase + c) * nAB + pos] : 0.f;
+    for (int i = 0; i < 8; ++i) out[i] = 0.f;
+
+    for (int branch = 0; branch < 2; ++branch) {
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        for (int ch = 0; ch < 16; ++ch) {
+            const float *src = H1 + (size_t)(branch * 16 + ch) * nAB;
+            __syncthreads();
+            // stage one channel: each wave copies whole rows (coalesced along the last axis)
+            for (int r = wave; r < nrows; r += 4) {
+                const int dc = r % hc, db = (r / hc) % hb, da = r / (hc * hb);
+                const int ia = a + da - 1, ib = b0 + db - 1, ic = c0 + dc - 1;
+                const bool rok = ia >= 0 && ia < v.d0 && ib >= 0 && ib < v.d1 && ic >= 0 && ic < v.d2;
+                const float *row = src + ((size_t)(ia * v.d1 + ib) * v.d2 + ic) * v.d3;
+                for (int col = lane; col < ncol; col += 64) {
+                    const int id = d0 + col - 1;
+                    tile2[r * t.rs + col] = (rok && id >= 0 && id < v.d3) ? row[id] : 0.f;
+                }
             }
             __syncthreads();
-            for (int c = 0; c < L2_CG; ++c)
+            if (active) {
+                const float *wch = w2cat + (branch * 16 + ch) * 81;
                 for (int da = 0; da < 3; ++da)
                     for (int db = 0; db < 3; ++db) {
-                        const float *tp = tile + c * HALO + ((da * HB_ + tb + db) * HC_ + tc) * HD_ + td;
-                        const float *wp = w2cat + (cbase + c) * 81 + (da * 3 + db) * 9;
 #pragma unroll
-                        for (int dc = 0; dc < 3; ++dc)
+                        for (int dc = 0; dc < 3; ++dc) {
+                            const float *p = tile2 + ((da * hb + rb + db) * hc + rc + dc) * t.rs + 8 * rr;
+                            const f32x4 x0 = *(const f32x4 *)p, x1 = *(const f32x4 *)(p + 4);
+                            const float x8 = p[8], x9 = p[9];
+                            const float x[10] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3], x8, x9};
+                            const float *w = wch + (da * 3 + db) * 9 + dc * 3;
+                            const float w0 = w[0], w1 = w[1], w2 = w[2];
 #pragma unroll
-                            for (int dd = 0; dd < 3; ++dd) acc = fmaf(tp[dc * HD_ + dd], wp[dc * 3 + dd], acc);
+                            for (int i = 0; i < 8; ++i)
+                                acc[i] = fmaf(x[i + 2], w2, fmaf(x[i + 1], w1, fmaf(x[i], w0, acc[i])));
+                        }
                     }
+            }
         }
-        out += fmaxf(acc + b2, 0.f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) out[i] += fmaxf(acc[i] + b2, 0.f);
     }
-    const int ib = b0 + tb, ic = c0 + tc, id = d0 + td;
-    if (ib < v.d1 && ic < v.d2 && id < v.d3) Y[(size_t)(a * v.d1 + ib) * nB + ic * v.d3 + id] = out;
+    if (active) {
+        const int ib = b0 + rb, ic = c0 + rc;
+        if (ib < v.d1 && ic < v.d2) {
+            float *dst = Y + ((size_t)(a * v.d1 + ib) * v.d2 + ic) * v.d3;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int id = d0 + 8 * rr + i;
+                if (id < v.d3) dst[id] = out[i];
+            }
+        }
+    }
+}
+
+// tile shape with the least padding for this volume (<= 256 runs, <= 52 KB of LDS so 3 groups fit a CU)
+static NcTile pick_nc_tile(const Vol &v) {
+    NcTile best{4, 8, 4, 36};
+    double best_eff = -1;
+    const int tbs[] = {2, 3, 4, 5, 6, 8}, tcs[] = {4, 5, 6, 8, 10, 12, 15, 16}, tdrs[] = {2, 3, 4, 5, 6, 8};
+    for (int tdr : tdrs)
+        for (int tb : tbs)
+            for (int tc : tcs) {
+                if (tb * tc * tdr > 256) continue;
+                const int rs = 8 * tdr + 4;
+                const size_t lds = (size_t)3 * (tb + 2) * (tc + 2) * rs * 4;
+                if (lds > 52 * 1024) continue;
+                const double groups = (double)v.d0 * ceil_div(v.d1, tb) * ceil_div(v.d2, tc) * ceil_div(v.d3, 8 * tdr);
+                const double useful = (double)v.d0 * v.d1 * v.d2 * v.d3;
+                // padding efficiency x halo efficiency (staged cells per useful output)
+                const double eff = useful / (groups * 256 * 8) *
+                                   ((double)tb * tc * 8 * tdr / ((tb + 2) * (tc + 2) * (8 * tdr + 2)));
+                if (eff > best_eff) { best_eff = eff; best = NcTile{tb, tc, tdr, rs}; }
+            }
+    return best;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -531,7 +591,10 @@ extern "C" int p2p_coarse_forward(const float *featA, const float *featB, int C,
     Vol v{hA / ksize, wA / ksize, hB / ksize, wB / ksize};
     const int ntiles = v.d0 * ceil_div(v.d1, TB_) * ceil_div(v.d2, TC_) * ceil_div(v.d3, TD_);
     hipLaunchKernelGGL(nc_layer1_kernel, dim3(ntiles), dim3(256), 0, stream, P, v, rkey1, ckey1, ncn->w1cat, ncn->b1cat, H1);
-    hipLaunchKernelGGL(nc_layer2_kernel, dim3(ntiles), dim3(256), 0, stream, H1, v, ncn->w2cat, ncn->b2, Y);
+    const NcTile nt = pick_nc_tile(v);
+    const int ntiles2 = v.d0 * ceil_div(v.d1, nt.tb) * ceil_div(v.d2, nt.tc) * ceil_div(v.d3, 8 * nt.tdr);
+    const size_t lds2 = (size_t)3 * (nt.tb + 2) * (nt.tc + 2) * nt.rs * 4;
+    hipLaunchKernelGGL(nc_layer2_kernel, dim3(ntiles2), dim3(256), lds2, stream, H1, v, nt, ncn->w2cat, ncn->b2, Y);
     hipLaunchKernelGGL(rowcolmax_kernel, mgrid, dim3(256), 0, stream, Y, nAc, nBc, rkey2, ckey2);
     const size_t nel = (size_t)nAc * nBc;
     hipLaunchKernelGGL(mm_apply_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, stream, Y, nAc, nBc, rkey2, ckey2,

@@ -30,8 +30,10 @@ constexpr int K1_CHUNKS_PER_TAP = 65;   // 1 (level-0 of both images, 6 ch padde
 constexpr int K1_CHUNKS = 9 * K1_CHUNKS_PER_TAP;
 constexpr int K2_CHUNKS_PER_TAP = 64;   // 512 channels / 8
 constexpr int K2_CHUNKS = 9 * K2_CHUNKS_PER_TAP;
-constexpr int WP1_FLOATS = 8 * (K1_CHUNKS + 1) * 2 * 64 * 4;   // +1 chunk: the prefetch runs one ahead
-constexpr int WP2_FLOATS = 8 * (K2_CHUNKS + 1) * 2 * 64 * 4;
+constexpr int PF = 2;                   // weight prefetch distance (chunks); buffers are padded by PF chunks
+constexpr int WP1_FLOATS = 8 * (K1_CHUNKS + PF) * 2 * 64 * 4;
+constexpr int WP2_FLOATS = 8 * (K2_CHUNKS + PF) * 2 * 64 * 4;
+constexpr int MAXB = 8;                 // image pairs per launch
 
 // LDS carve-up (floats)
 constexpr int TILE_L0 = 0, TILE_L1 = 768, TILE_L2 = 5952, TILE_L3 = 7552, TILE_IMG = 8704;
@@ -50,9 +52,15 @@ struct RegDev {
     const float *fc1t, *fc1b, *bnf1s, *bnf1b, *fc2t, *fc2b, *bnf2s, *bnf2b, *fc3, *fc3b;
 };
 
-struct RegressArgs {
+struct ItemDev {
     const float *pyr[2][4];
     int H[2], W[2];
+};
+
+struct RegressArgs {
+    ItemDev item[MAXB];
+    int start[MAXB + 1];          // proposal range of each item in the concatenated arrays
+    int nitems;
     const void *proposals;
     int is_float, n, nlevels;
     RegDev reg[2];
@@ -80,6 +88,9 @@ __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
     const int half = lane >> 5;
     const int l31 = lane & 31;
     const int prop = blockIdx.x;
+    int it = 0;
+    while (it + 1 < args.nitems && prop >= args.start[it + 1]) ++it;
+    const ItemDev &I = args.item[it];
 
     float *tiles = smem;
     float *Hbuf = smem;
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
 
         // ---------------------------------------------------------------- gather (dedup tiles)
         for (int img = 0; img < 2; ++img) {
-            const int Hh = args.H[img], Ww = args.W[img];
+            const int Hh = I.H[img], Ww = I.W[img];
             float *t = tiles + img * TILE_IMG;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -119,7 +130,7 @@ __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
                 const int Hj = Hh >> j, Wj = Ww >> j;
                 const int r0 = clampi(y0[img] >> j, 0, Hj - 1);
                 const int c0 = clampi(x0[img] >> j, 0, Wj - 1);
-                const float *src = args.pyr[img][j];
+                const float *src = I.pyr[img][j];
                 for (int e = tid; e < Cc * Rr * Rr; e += NT) {
                     const int c = e / (Rr * Rr);
                     const int rem = e - c * (Rr * Rr);
@@ -145,7 +156,7 @@ __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
             const float *t = tiles + img * TILE_IMG;
             float ss = 0.f;
             {
-                const float *p = t + TILE_L0 + cell(y0[img], py, 0, args.H[img]) * 16 + cell(x0[img], px, 0, args.W[img]);
+                const float *p = t + TILE_L0 + cell(y0[img], py, 0, I.H[img]) * 16 + cell(x0[img], px, 0, I.W[img]);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { float v = p[c * 256]; ss = fmaf(v, v, ss); }
             }
@@ -154,7 +165,7 @@ __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
                 const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
                 const int Cc = (j == 3) ? 128 : 64;
                 const int off = (j == 1) ? TILE_L1 : (j == 2) ? TILE_L2 : TILE_L3;
-                const float *p = t + off + cell(y0[img], py, j, args.H[img]) * Rr + cell(x0[img], px, j, args.W[img]);
+                const float *p = t + off + cell(y0[img], py, j, I.H[img]) * Rr + cell(x0[img], px, j, I.W[img]);
                 for (int c = 0; c < Cc; ++c) { float v = p[c * Rr * Rr]; ss = fmaf(v, v, ss); }
             }
             scale[tid] = 1.0f / sqrtf(ss + 1e-6f);
@@ -164,8 +175,9 @@ __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
         // ---------------------------------------------------------------- conv1: 3x3, stride 2, pad 1
         f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
         {
-            const f32x4 *bp = (const f32x4 *)R.wp1 + (size_t)wave * (K1_CHUNKS + 1) * 128 + lane;
-            f32x4 b0 = bp[0], b1 = bp[64];
+            // weight stream: b* = current chunk, c* = next chunk, the loads issued below are two ahead
+            const f32x4 *bp = (const f32x4 *)R.wp1 + (size_t)wave * (K1_CHUNKS + PF) * 128 + lane;
+            f32x4 b0 = bp[0], b1 = bp[64], c0 = bp[128], c1 = bp[192];
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap - ky * 3;
                 // per-lane source pixel of both m-tiles for this tap
@@ -182,17 +194,17 @@ __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
                 float a0[4], a1[4];
                 // --- chunk 0: level 0 of both images; k = 2q+half -> (img0 c0,c1,c2, img1 c0,c1,c2, 0, 0)
                 {
-                    f32x4 nb0 = bp[128], nb1 = bp[192];
+                    f32x4 n0 = bp[256], n1 = bp[320];
                     bp += 128;
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const int pofs = pyc[t] * 16 + pxc[t];
                         const float s0 = ok[t] ? scale[pofs] : 0.f;
                         const float s1 = ok[t] ? scale[256 + pofs] : 0.f;
-                        const float *t0 = tiles + TILE_L0 + cell(y0[0], pyc[t], 0, args.H[0]) * 16 +
-                                          cell(x0[0], pxc[t], 0, args.W[0]);
-                        const float *t1 = tiles + TILE_IMG + TILE_L0 + cell(y0[1], pyc[t], 0, args.H[1]) * 16 +
-                                          cell(x0[1], pxc[t], 0, args.W[1]);
+                        const float *t0 = tiles + TILE_L0 + cell(y0[0], pyc[t], 0, I.H[0]) * 16 +
+                                          cell(x0[0], pxc[t], 0, I.W[0]);
+                        const float *t1 = tiles + TILE_IMG + TILE_L0 + cell(y0[1], pyc[t], 0, I.H[1]) * 16 +
+                                          cell(x0[1], pxc[t], 0, I.W[1]);
                         float v0 = t0[half * 256] * s0;                                   // img0 c0 | c1
                         float v1 = half ? t1[0] * s1 : t0[512] * s0;                      // img0 c2 | img1 c0
                         float v2 = t1[(1 + half) * 256] * s1;                             // img1 c1 | c2
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
                         else        { a1[0] = v0; a1[1] = v1; a1[2] = v2; a1[3] = 0.f; }
                     }
                     P2P_CHUNK_MFMA(a0, a1)
-                    b0 = nb0; b1 = nb1;
+                    b0 = c0; b1 = c1; c0 = n0; c1 = n1;
                 }
                 // --- chunks 1..64: (img, level 1..3) segments, 8 channels per chunk
                 for (int img = 0; img < 2; ++img) {
@@ -213,20 +225,27 @@ __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
                         const int nchunk = (j == 3) ? 16 : 8;
                         const int off = (j == 1) ? TILE_L1 : (j == 2) ? TILE_L2 : TILE_L3;
                         const float *base = tiles + img * TILE_IMG + off + half * CS;
-                        const float *p0 = base + cell(y0[img], pyc[0], j, args.H[img]) * Rr +
-                                          cell(x0[img], pxc[0], j, args.W[img]);
-                        const float *p1 = base + cell(y0[img], pyc[1], j, args.H[img]) * Rr +
-                                          cell(x0[img], pxc[1], j, args.W[img]);
+                        const float *p0 = base + cell(y0[img], pyc[0], j, I.H[img]) * Rr +
+                                          cell(x0[img], pxc[0], j, I.W[img]);
+                        const float *p1 = base + cell(y0[img], pyc[1], j, I.H[img]) * Rr +
+                                          cell(x0[img], pxc[1], j, I.W[img]);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { a0[q] = p0[2 * q * CS] * s0; a1[q] = p1[2 * q * CS] * s1; }
                         for (int ch = 0; ch < nchunk; ++ch) {
-                            f32x4 nb0 = bp[128], nb1 = bp[192];
+                            f32x4 n0 = bp[256], n1 = bp[320];
                             bp += 128;
+                            // A fragments of the next chunk (re-reads the last one at the segment end)
+                            const int chn = min(ch + 1, nchunk - 1);
+                            float an0[4], an1[4];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                a0[q] = p0[(ch * 8 + 2 * q) * CS] * s0;
-                                a1[q] = p1[(ch * 8 + 2 * q) * CS] * s1;
+                                an0[q] = p0[(chn * 8 + 2 * q) * CS];
+                                an1[q] = p1[(chn * 8 + 2 * q) * CS];
                             }
                             P2P_CHUNK_MFMA(a0, a1)
-                            b0 = nb0; b1 = nb1;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { a0[q] = an0[q] * s0; a1[q] = an1[q] * s1; }
+                            b0 = c0; b1 = c1; c0 = n0; c1 = n1;
                         }
                     }
                 }
@@ -260,8 +279,8 @@ __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
         // ---------------------------------------------------------------- conv2: 3x3, stride 1, pad 1
         acc00 = (f32x16){0}; acc01 = (f32x16){0}; acc10 = (f32x16){0}; acc11 = (f32x16){0};
         {
-            const f32x4 *bp = (const f32x4 *)R.wp2 + (size_t)wave * (K2_CHUNKS + 1) * 128 + lane;
-            f32x4 b0 = bp[0], b1 = bp[64];
+            const f32x4 *bp = (const f32x4 *)R.wp2 + (size_t)wave * (K2_CHUNKS + PF) * 128 + lane;
+            f32x4 b0 = bp[0], b1 = bp[64], c0 = bp[128], c1 = bp[192];
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap - ky * 3;
                 const float *p0, *p1;
@@ -276,17 +295,23 @@ __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
                     p0 = Hbuf + half * HSTRIDE + (ok0 ? oy * 8 + ox : 0);
                     p1 = Hbuf + half * HSTRIDE + (ok1 ? (oy + 4) * 8 + ox : 0);
                 }
+                float a0[4], a1[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { a0[q] = p0[2 * q * HSTRIDE] * m0; a1[q] = p1[2 * q * HSTRIDE] * m1; }
                 for (int ch = 0; ch < K2_CHUNKS_PER_TAP; ++ch) {
-                    f32x4 nb0 = bp[128], nb1 = bp[192];
+                    f32x4 n0 = bp[256], n1 = bp[320];
                     bp += 128;
-                    float a0[4], a1[4];
+                    const int chn = min(ch + 1, K2_CHUNKS_PER_TAP - 1);
+                    float an0[4], an1[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        a0[q] = p0[(ch * 8 + 2 * q) * HSTRIDE] * m0;
-                        a1[q] = p1[(ch * 8 + 2 * q) * HSTRIDE] * m1;
+                        an0[q] = p0[(chn * 8 + 2 * q) * HSTRIDE];
+                        an1[q] = p1[(chn * 8 + 2 * q) * HSTRIDE];
                     }
                     P2P_CHUNK_MFMA(a0, a1)
-                    b0 = nb0; b1 = nb1;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { a0[q] = an0[q] * m0; a1[q] = an1[q] * m1; }
+                    b0 = c0; b1 = c1; c0 = n0; c1 = n1;
                 }
             }
         }
@@ -353,7 +378,7 @@ __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
             if (tid < 4) {
                 const float off = 16.0f * tanhf(fmaxf(s, 0.f)) - 8.0f;
                 float fm = misc[8 + tid] + off;
-                const float hi = (float)((tid & 1) ? args.H[tid >> 1] : args.W[tid >> 1]);
+                const float hi = (float)((tid & 1) ? I.H[tid >> 1] : I.W[tid >> 1]);
                 fm = fminf(fmaxf(fm, 0.f), hi);
                 if (args.matches[lvl]) args.matches[lvl][(size_t)prop * 4 + tid] = fm;
                 misc[8 + tid] = fm;       // becomes the next level's proposal (un-truncated)
@@ -422,7 +447,7 @@ extern "C" int p2p_regressor_create(const p2p_regressor_params *p, p2p_regressor
                     for (int q = 0; q < 4; ++q) {
                         const int n = 64 * w + 32 * u + (lane & 31);
                         const int ch = conv1_channel_of(8 * kin + 2 * q + (lane >> 5));
-                        const size_t dst = o_wp1 + ((((size_t)w * (K1_CHUNKS + 1) + kc) * 2 + u) * 64 + lane) * 4 + q;
+                        const size_t dst = o_wp1 + ((((size_t)w * (K1_CHUNKS + PF) + kc) * 2 + u) * 64 + lane) * 4 + q;
                         h[dst] = (ch < 0) ? 0.f : p->conv1_w[((size_t)n * 518 + ch) * 9 + tap];
                     }
         }
@@ -435,7 +460,7 @@ extern "C" int p2p_regressor_create(const p2p_regressor_params *p, p2p_regressor
                     for (int q = 0; q < 4; ++q) {
                         const int n = 64 * w + 32 * u + (lane & 31);
                         const int ch = 8 * kin + 2 * q + (lane >> 5);
-                        const size_t dst = o_wp2 + ((((size_t)w * (K2_CHUNKS + 1) + kc) * 2 + u) * 64 + lane) * 4 + q;
+                        const size_t dst = o_wp2 + ((((size_t)w * (K2_CHUNKS + PF) + kc) * 2 + u) * 64 + lane) * 4 + q;
                         h[dst] = p->conv2_w[((size_t)n * 512 + ch) * 9 + tap];
                     }
         }
@@ -486,41 +511,82 @@ static RegDev to_dev(const p2p_regressor *r) {
     return d;
 }
 
+extern "C" int p2p_regress_batch(const p2p_regressor *reg1, const p2p_regressor *reg2, int nitems,
+                                 const p2p_pyramid *im1, const p2p_pyramid *im2, const int *counts,
+                                 const void *proposals, int is_float,
+                                 float *matches1, float *probs1, float *raw1,
+                                 float *matches2, float *probs2, float *raw2, p2p_stream_t stream) {
+    P2P_REQUIRE(reg1 && im1 && im2 && counts, P2P_EINVAL, "p2p_regress: null argument");
+    P2P_REQUIRE(nitems >= 0, P2P_EINVAL, "p2p_regress: negative item count");
+    long long total = 0;
+    for (int i = 0; i < nitems; ++i) {
+        P2P_REQUIRE(counts[i] >= 0, P2P_EINVAL, "p2p_regress: negative proposal count");
+        total += counts[i];
+    }
+    if (total == 0) return P2P_OK;
+    P2P_REQUIRE(total < (1ll << 31), P2P_EINVAL, "p2p_regress: too many proposals");
+    P2P_REQUIRE(proposals, P2P_EINVAL, "p2p_regress: null proposals");
+    P2P_REQUIRE(reg2 ? (matches2 && probs2) : (matches1 && probs1), P2P_EINVAL, "p2p_regress: missing output buffers");
+    for (int i = 0; i < nitems; ++i) {
+        const p2p_pyramid *im[2] = {im1 + i, im2 + i};
+        for (int s = 0; s < 2; ++s) {
+            P2P_REQUIRE(im[s]->height > 0 && im[s]->width > 0 && im[s]->height % 8 == 0 && im[s]->width % 8 == 0,
+                        P2P_EINVAL, "p2p_regress: item %d image %d size %dx%d must be positive multiples of 8", i, s + 1,
+                        im[s]->height, im[s]->width);
+            for (int j = 0; j < 4; ++j) P2P_REQUIRE(im[s]->level[j], P2P_EINVAL, "p2p_regress: null pyramid level");
+        }
+    }
+    int dev = 0;
+    P2P_HIP_CHECK(hipGetDevice(&dev));
+    static bool attr_set[64] = {false};
+    if (dev < 64 && !attr_set[dev]) {
+        P2P_HIP_CHECK(hipFuncSetAttribute((const void *)regress_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)LDS_BYTES));
+        attr_set[dev] = true;
+    }
+    // launches of at most MAXB items; outputs/proposals are indexed by the global proposal number
+    int first_prop = 0;
+    for (int i0 = 0; i0 < nitems; i0 += MAXB) {
+        const int nb = (nitems - i0 < MAXB) ? nitems - i0 : MAXB;
+        RegressArgs a;
+        int n = 0;
+        for (int b = 0; b < nb; ++b) {
+            const p2p_pyramid *im[2] = {im1 + i0 + b, im2 + i0 + b};
+            for (int s = 0; s < 2; ++s) {
+                for (int j = 0; j < 4; ++j) a.item[b].pyr[s][j] = im[s]->level[j];
+                a.item[b].H[s] = im[s]->height;
+                a.item[b].W[s] = im[s]->width;
+            }
+            a.start[b] = n;
+            n += counts[i0 + b];
+        }
+        for (int b = nb; b <= MAXB; ++b) a.start[b] = n;
+        for (int b = nb; b < MAXB; ++b) a.item[b] = a.item[0];
+        a.nitems = nb;
+        a.is_float = is_float; a.n = n; a.nlevels = reg2 ? 2 : 1;
+        a.proposals = is_float ? (const void *)((const float *)proposals + (size_t)first_prop * 4)
+                               : (const void *)((const long long *)proposals + (size_t)first_prop * 4);
+        a.reg[0] = to_dev(reg1);
+        a.reg[1] = reg2 ? to_dev(reg2) : a.reg[0];
+        auto adv = [&](float *p, int cols) { return p ? p + (size_t)first_prop * cols : nullptr; };
+        a.matches[0] = adv(matches1, 4); a.probs[0] = adv(probs1, 1); a.raw[0] = adv(raw1, 5);
+        a.matches[1] = adv(matches2, 4); a.probs[1] = adv(probs2, 1); a.raw[1] = adv(raw2, 5);
+        if (n > 0) {
+            hipLaunchKernelGGL(regress_kernel, dim3(n), dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+            const int st = check_launch("regress_kernel");
+            if (st != P2P_OK) return st;
+        }
+        first_prop += n;
+    }
+    return P2P_OK;
+}
+
 extern "C" int p2p_regress(const p2p_regressor *reg1, const p2p_regressor *reg2,
                            const p2p_pyramid *im1, const p2p_pyramid *im2,
                            const void *proposals, int is_float, int n,
                            float *matches1, float *probs1, float *raw1,
                            float *matches2, float *probs2, float *raw2, p2p_stream_t stream) {
-    P2P_REQUIRE(reg1 && im1 && im2, P2P_EINVAL, "p2p_regress: null argument");
     P2P_REQUIRE(n >= 0, P2P_EINVAL, "p2p_regress: negative proposal count");
-    if (n == 0) return P2P_OK;
-    P2P_REQUIRE(proposals, P2P_EINVAL, "p2p_regress: null proposals");
-    P2P_REQUIRE(reg2 ? (matches2 && probs2) : (matches1 && probs1), P2P_EINVAL, "p2p_regress: missing output buffers");
-    const p2p_pyramid *im[2] = {im1, im2};
-    RegressArgs a;
-    for (int i = 0; i < 2; ++i) {
-        P2P_REQUIRE(im[i]->height > 0 && im[i]->width > 0 && im[i]->height % 8 == 0 && im[i]->width % 8 == 0,
-                    P2P_EINVAL, "p2p_regress: image %d size %dx%d must be positive multiples of 8", i + 1,
-                    im[i]->height, im[i]->width);
-        for (int j = 0; j < 4; ++j) {
-            P2P_REQUIRE(im[i]->level[j], P2P_EINVAL, "p2p_regress: null pyramid level");
-            a.pyr[i][j] = im[i]->level[j];
-        }
-        a.H[i] = im[i]->height;
-        a.W[i] = im[i]->width;
-    }
-    a.proposals = proposals; a.is_float = is_float; a.n = n; a.nlevels = reg2 ? 2 : 1;
-    a.reg[0] = to_dev(reg1);
-    a.reg[1] = reg2 ? to_dev(reg2) : a.reg[0];
-    a.matches[0] = matches1; a.probs[0] = probs1; a.raw[0] = raw1;
-    a.matches[1] = matches2; a.probs[1] = probs2; a.raw[1] = raw2;
-
-    static bool attr_set = false;
-    if (!attr_set) {
-        P2P_HIP_CHECK(hipFuncSetAttribute((const void *)regress_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)LDS_BYTES));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(regress_kernel, dim3(n), dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
-    return check_launch("regress_kernel");
+    return p2p_regress_batch(reg1, reg2, 1, im1, im2, &n, proposals, is_float, matches1, probs1, raw1, matches2, probs2,
+                             raw2, stream);
 }

@@ -1,0 +1,38 @@
+"""Pair-level data parallelism: one process per GPU, pairs sharded by rank, and a single exchange
+step -- the gather of the (ragged) match arrays over RCCL/xGMI (gloo on CPU in the tests).
+The reference is single-device (model_helper.py:30); pairs are independent, so no collective is
+needed on the data path itself."""
+import torch
+import torch.distributed as dist
+
+
+def shard_pairs(num_pairs, rank, world):
+    """Pair ids handled by `rank` (round-robin, deterministic, covers every id exactly once)."""
+    return list(range(rank, num_pairs, world))
+
+
+def gather_matches(rows, pair_ids, group=None):
+    """All-gather ragged per-rank results.
+
+    rows:     [M, C] float tensor (e.g. C = 9: fine x1,y1,x2,y2, score, coarse x1,y1,x2,y2)
+    pair_ids: [M] int64 tensor, the pair each row belongs to
+    Returns (rows_all [sum M, C], pair_ids_all [sum M]) ordered by rank then local order, on every rank.
+    Two collectives: counts (int64 [1] per rank), then one padded payload all_gather.
+    """
+    if not (dist.is_available() and dist.is_initialized()):
+        return rows, pair_ids
+    world = dist.get_world_size(group)
+    dev = rows.device
+    count = torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count, group=group)
+    counts = [int(c.item()) for c in counts]
+    cap = max(max(counts), 1)
+    c = rows.shape[1]
+    payload = torch.zeros((cap, c + 1), dtype=torch.float64 if rows.dtype == torch.float64 else torch.float32, device=dev)
+    payload[:rows.shape[0], :c] = rows
+    payload[:rows.shape[0], c] = pair_ids.to(payload.dtype)      # exact for ids < 2^24
+    gathered = [torch.empty_like(payload) for _ in range(world)]
+    dist.all_gather(gathered, payload, group=group)
+    out = torch.cat([g[:n] for g, n in zip(gathered, counts)])
+    return out[:, :c].to(rows.dtype), out[:, c].round().to(torch.int64)

@@ -166,13 +166,16 @@ class Patch2Pix(nn.Module):
     # ------------------------------------------------------------------ coarse stage
     def forward_coarse_match(self, feat1, feat2, ksize=1):
         ncn = self._weights()[0]
-        corr, packed = [], []
-        for b in range(feat1.shape[0]):
-            c, d = ops.coarse_forward(feat1[b], feat2[b], ksize, ncn)
-            corr.append(c)
-            packed.append(d)
-        corr4d = torch.stack(corr).unsqueeze(1)
-        delta4d = Delta4d(packed, ksize) if ksize > 1 else None
+        b, _, h1, w1 = feat1.shape
+        _, _, h2, w2 = feat2.shape
+        k = max(ksize, 1)
+        shape = (b, 1, h1 // k, w1 // k, h2 // k, w2 // k)
+        corr4d = torch.empty(shape, dtype=torch.float32, device=feat1.device)
+        packed = torch.empty(shape, dtype=torch.uint8, device=feat1.device) if ksize > 1 else None
+        for i in range(b):
+            ops.coarse_forward(feat1[i], feat2[i], ksize, ncn, out_corr=corr4d[i, 0],
+                               out_delta=packed[i, 0] if packed is not None else None)
+        delta4d = Delta4d([packed[i, 0] for i in range(b)], ksize) if ksize > 1 else None
         return corr4d, delta4d
 
     def forward(self, im1, im2, ksize=1, return_feats=False):
@@ -196,13 +199,13 @@ class Patch2Pix(nn.Module):
             di, dj, dk, dl = delta4d            # reference-format int64 planes -> packed byte
             s = ((di * ksize + dj) * ksize + dk) * ksize + dl
             delta4d = Delta4d([p[0].to(torch.uint8).contiguous() for p in s], ksize)
-        matches, scores = [], []
-        for b in range(corr4d.shape[0]):
-            m, s = ops.coarse_matches(corr4d[b, 0], delta4d.packed[b] if delta4d is not None else None,
-                                      ksize, upsample, center)
-            matches.append(m)
-            scores.append(s)
-        matches_, score_ = torch.stack(matches), torch.stack(scores)
+        nb, _, h1, w1, h2, w2 = corr4d.shape
+        n = h1 * w1 + h2 * w2
+        matches_ = torch.empty((nb, n, 4), dtype=torch.int64, device=corr4d.device)
+        score_ = torch.empty((nb, n), dtype=torch.float32, device=corr4d.device)
+        for b in range(nb):
+            ops.coarse_matches(corr4d[b, 0], delta4d.packed[b] if delta4d is not None else None,
+                               ksize, upsample, center, out_matches=matches_[b], out_scores=score_[b])
         if sort:
             order = torch.sort(-score_)[1]
             score_ = torch.gather(score_, 1, order)
@@ -224,13 +227,11 @@ class Patch2Pix(nn.Module):
         `self.regress_mid` / `self.regress_fine` like in the reference call sites."""
         _, mid_w, fine_w = self._weights()
         w = fine_w if (regressor is self.regress_fine and regressor is not self.regress_mid) else mid_w
-        fine_matches, masks = [], []
-        for b, props in enumerate(coarse_matches):
-            props = self._as_proposals(props)
-            out = ops.regress(w, None, [f[b] for f in feats1[:4]], [f[b] for f in feats2[:4]], props)
-            fine_matches.append(out["matches1"])
-            masks.append(out["probs1"])
-        return fine_matches, masks
+        nb = len(coarse_matches)
+        outs = ops.regress_batch(w, None, [[f[b] for f in feats1[:4]] for b in range(nb)],
+                                 [[f[b] for f in feats2[:4]] for b in range(nb)],
+                                 [self._as_proposals(p) for p in coarse_matches])
+        return [o["matches1"] for o in outs], [o["probs1"] for o in outs]
 
     def _as_proposals(self, props):
         props = props.to(self.device)
@@ -241,13 +242,12 @@ class Patch2Pix(nn.Module):
     def _fine_chain(self, feats1, feats2, coarse_matches):
         """mid -> fine for every batch item in one launch each (patch2pix.py:259-272)."""
         _, mid_w, fine_w = self._weights()
-        mids, mid_scores, fines, fine_scores = [], [], [], []
-        for b, props in enumerate(coarse_matches):
-            out = ops.regress(mid_w, fine_w, [f[b] for f in feats1[:4]], [f[b] for f in feats2[:4]],
-                              self._as_proposals(props))
-            mids.append(out["matches1"]); mid_scores.append(out["probs1"])
-            fines.append(out["matches2"]); fine_scores.append(out["probs2"])
-        return fines, fine_scores, mids, mid_scores
+        nb = len(coarse_matches)
+        outs = ops.regress_batch(mid_w, fine_w, [[f[b] for f in feats1[:4]] for b in range(nb)],
+                                 [[f[b] for f in feats2[:4]] for b in range(nb)],
+                                 [self._as_proposals(p) for p in coarse_matches])
+        return ([o["matches2"] for o in outs], [o["probs2"] for o in outs],
+                [o["matches1"] for o in outs], [o["probs1"] for o in outs])
 
     # ------------------------------------------------------------------ public prediction API
     def predict_coarse(self, im1, im2, ksize=2, ncn_thres=0.0, mutual=False, center=True):

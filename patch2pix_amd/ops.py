@@ -90,9 +90,9 @@ def _workspace(device, nbytes):
     return ws
 
 
-def coarse_forward(feat_a, feat_b, ksize, ncn, want_delta=True):
+def coarse_forward(feat_a, feat_b, ksize, ncn, want_delta=True, out_corr=None, out_delta=None):
     """forward_coarse_match for one pair.  feat_*: [C,h,w] fp32 GPU.  Returns (corr [hA',wA',hB',wB'],
-    packed delta uint8 of the same shape or None)."""
+    packed delta uint8 of the same shape or None); `out_*` let the caller provide (contiguous) outputs."""
     feat_a, feat_b = _f32c(feat_a, "feat_a"), _f32c(feat_b, "feat_b")
     c, ha, wa = feat_a.shape
     c2, hb, wb = feat_b.shape
@@ -104,8 +104,12 @@ def coarse_forward(feat_a, feat_b, ksize, ncn, want_delta=True):
         ws = _workspace(dev, max(nbytes, 256))
         k = max(ksize, 1)
         shape = (ha // k, wa // k, hb // k, wb // k)
-        corr = torch.empty(shape, dtype=torch.float32, device=dev)
-        delta = torch.empty(shape, dtype=torch.uint8, device=dev) if (ksize > 1 and want_delta) else None
+        corr = out_corr if out_corr is not None else torch.empty(shape, dtype=torch.float32, device=dev)
+        delta = None
+        if ksize > 1 and want_delta:
+            delta = out_delta if out_delta is not None else torch.empty(shape, dtype=torch.uint8, device=dev)
+        assert corr.is_contiguous() and tuple(corr.shape) == shape and corr.dtype == torch.float32
+        assert delta is None or (delta.is_contiguous() and tuple(delta.shape) == shape and delta.dtype == torch.uint8)
         _lib.check(_lib.p2p_coarse_forward(feat_a.data_ptr(), feat_b.data_ptr(), c, ha, wa, hb, wb, ksize, ncn.handle,
                                            corr.data_ptr(), delta.data_ptr() if delta is not None else None,
                                            ws.data_ptr(), ws.numel(), _stream()), "p2p_coarse_forward")
@@ -121,14 +125,16 @@ def delta_unpack(delta, ksize):
     return out[0], out[1], out[2], out[3]
 
 
-def coarse_matches(corr, delta, ksize, upsample, center=True):
+def coarse_matches(corr, delta, ksize, upsample, center=True, out_matches=None, out_scores=None):
     """cal_coarse_matches for one pair: ([nB+nA,4] int64 pixel matches, [nB+nA] fp32 scores)."""
     corr = _f32c(corr, "corr4d")
     ha, wa, hb, wb = corr.shape
     n = ha * wa + hb * wb
     dev = corr.device
-    matches = torch.empty((n, 4), dtype=torch.int64, device=dev)
-    scores = torch.empty((n,), dtype=torch.float32, device=dev)
+    matches = out_matches if out_matches is not None else torch.empty((n, 4), dtype=torch.int64, device=dev)
+    scores = out_scores if out_scores is not None else torch.empty((n,), dtype=torch.float32, device=dev)
+    assert matches.is_contiguous() and tuple(matches.shape) == (n, 4) and matches.dtype == torch.int64
+    assert scores.is_contiguous() and tuple(scores.shape) == (n,) and scores.dtype == torch.float32
     if delta is not None:
         delta = delta.contiguous()
     with torch.cuda.device(dev):
@@ -154,29 +160,44 @@ def _pyramid(levels):
     return p, lv
 
 
-def regress(reg1, reg2, pyr1, pyr2, proposals, want_mid=True, want_raw=False):
-    """forward_fine_match for one pair; with reg2 the mid->fine chain runs in the same launch.
+def regress_batch(reg1, reg2, pyrs1, pyrs2, proposals, want_mid=True, want_raw=False):
+    """forward_fine_match for a list of pairs in ONE launch; with reg2 the mid->fine chain runs inside it.
 
-    proposals: [n,4] int64 or float32 on the GPU.  Returns a dict with 'matches1','probs1'
-    (and 'matches2','probs2' when reg2 is given; 'raw*' on request)."""
-    dev = proposals.device
-    if proposals.dtype == torch.int64:
+    pyrs1/pyrs2: per pair, the 4 maps of feat_idx [0,1,2,3]; proposals: per pair [n_i,4] int64 or
+    float32 (same dtype for all).  Returns a list of dicts 'matches1','probs1' (+ 'matches2','probs2'
+    when reg2 is given; 'raw*' on request), views into shared buffers."""
+    nitems = len(proposals)
+    if nitems == 0:
+        return []
+    dev = proposals[0].device
+    dtype = proposals[0].dtype
+    if dtype == torch.int64:
         is_float = 0
-    elif proposals.dtype == torch.float32:
+    elif dtype == torch.float32:
         is_float = 1
     else:
         raise TypeError("proposals must be int64 or float32")
-    proposals = proposals.contiguous()
-    n = proposals.shape[0]
-    p1, keep1 = _pyramid(pyr1)
-    p2, keep2 = _pyramid(pyr2)
-    out = {}
+    if any(p.dtype != dtype for p in proposals):
+        raise TypeError("all proposal arrays of a batch must share one dtype")
+    counts = [int(p.shape[0]) for p in proposals]
+    n = sum(counts)
+    allp = proposals[0].contiguous() if nitems == 1 else torch.cat([p.reshape(-1, 4) for p in proposals])
+    pyr_a = (_lib.Pyramid * nitems)()
+    pyr_b = (_lib.Pyramid * nitems)()
+    keep = []
+    for i in range(nitems):
+        pa, ka = _pyramid(pyrs1[i])
+        pb, kb = _pyramid(pyrs2[i])
+        pyr_a[i], pyr_b[i] = pa, pb
+        keep.append((ka, kb))
+    cnt = (ctypes.c_int * nitems)(*counts)
+    bufs = {}
 
     def buf(key, cols, cond=True):
         if not cond:
             return None
-        out[key] = torch.empty((n, cols) if cols > 1 else (n,), dtype=torch.float32, device=dev)
-        return out[key].data_ptr()
+        bufs[key] = torch.empty((n, cols) if cols > 1 else (n,), dtype=torch.float32, device=dev)
+        return bufs[key].data_ptr()
 
     two = reg2 is not None
     m1 = buf("matches1", 4, want_mid or not two)
@@ -191,11 +212,20 @@ def regress(reg1, reg2, pyr1, pyr2, proposals, want_mid=True, want_raw=False):
             if regress_events is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            _lib.check(_lib.p2p_regress(reg1.handle, reg2.handle if two else None, ctypes.byref(p1), ctypes.byref(p2),
-                                        proposals.data_ptr(), is_float, n, m1, q1, r1, m2, q2, r2, _stream()),
-                       "p2p_regress")
+            _lib.check(_lib.p2p_regress_batch(reg1.handle, reg2.handle if two else None, nitems, pyr_a, pyr_b, cnt,
+                                              allp.data_ptr(), is_float, m1, q1, r1, m2, q2, r2, _stream()),
+                       "p2p_regress_batch")
             if ev is not None:
                 ev[1].record()
                 regress_events.append((ev[0], ev[1], n, 2 if two else 1))
-    del keep1, keep2
-    return out
+    del keep
+    outs, start = [], 0
+    for c in counts:
+        outs.append({k: v[start:start + c] for k, v in bufs.items()})
+        start += c
+    return outs
+
+
+def regress(reg1, reg2, pyr1, pyr2, proposals, want_mid=True, want_raw=False):
+    """Single-pair form of regress_batch (returns one dict)."""
+    return regress_batch(reg1, reg2, [pyr1], [pyr2], [proposals], want_mid, want_raw)[0]

@@ -1,0 +1,61 @@
+"""The N>1 path of bench.py on CPU: two gloo processes shard a pair list and gather ragged match arrays."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from patch2pix_amd.gather import gather_matches, shard_pairs
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _fake_rows(pair_id):
+    n = (pair_id * 7) % 5                      # ragged, includes empty results
+    g = torch.Generator().manual_seed(pair_id)
+    return torch.rand(n, 9, generator=g) + pair_id
+
+
+def _worker(rank, world, port, num_pairs, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard_pairs(num_pairs, rank, world)
+    rows = [_fake_rows(p) for p in mine]
+    ids = [torch.full((r.shape[0],), p, dtype=torch.int64) for r, p in zip(rows, mine)]
+    rows_all, ids_all = gather_matches(torch.cat(rows) if rows else torch.zeros(0, 9),
+                                       torch.cat(ids) if ids else torch.zeros(0, dtype=torch.int64))
+    ret[rank] = (rows_all, ids_all)
+    dist.destroy_process_group()
+
+
+def test_shard_covers_every_pair_once():
+    for world in (1, 2, 3, 8):
+        seen = sorted(p for r in range(world) for p in shard_pairs(11, r, world))
+        assert seen == list(range(11))
+
+
+def test_two_rank_gather_of_ragged_matches():
+    world, num_pairs = 2, 9
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, num_pairs, ret), nprocs=world, join=True)
+    assert set(ret.keys()) == {0, 1}
+    r0, i0 = ret[0]
+    r1, i1 = ret[1]
+    assert torch.equal(r0, r1) and torch.equal(i0, i1)          # every rank holds the same gathered set
+    for p in range(num_pairs):                                   # and it is exactly the union of the shards
+        assert torch.equal(r0[i0 == p], _fake_rows(p))
+    assert r0.shape[0] == sum((p * 7) % 5 for p in range(num_pairs))
+
+
+def test_single_process_is_identity():
+    rows = torch.rand(4, 9)
+    ids = torch.arange(4)
+    a, b = gather_matches(rows, ids)
+    assert a is rows and b is ids

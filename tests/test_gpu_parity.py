@@ -214,3 +214,24 @@ def test_estimate_matches_golden(name, dev, tmp_path):
     mc, sc, cc = model_helper.estimate_matches(net, str(tmp_path / "1.png"), str(tmp_path / "2.png"), ksize=2,
                                                ncn_thres=0.0, eval_type="coarse", imsize=imsize)
     assert mc.shape[1] == 4 and np.array_equal(mc, cc)
+
+
+def test_batched_launch_equals_per_pair(dev, ops, weights):
+    """p2p_regress_batch over pairs of *different* sizes == one launch per pair (bit-exact),
+    including an empty item and more items than one launch holds."""
+    _, _, mid_w, fine_w = weights
+    sizes = [(48, 64), (96, 128), (64, 48), (48, 64), (80, 80), (48, 64), (96, 64), (64, 64), (48, 96), (56, 72)]
+    g = torch.Generator().manual_seed(3)
+    pyr1, pyr2, props = [], [], []
+    for i, (H, W) in enumerate(sizes):
+        pyr1.append(_gpu(synthetic.make_pyramid(200 + i, H, W)[:4], dev))
+        pyr2.append(_gpu(synthetic.make_pyramid(300 + i, H, W)[:4], dev))
+        n = 0 if i == 3 else 5 + 3 * i
+        props.append(torch.stack([torch.randint(0, W + 1, (n,), generator=g), torch.randint(0, H + 1, (n,), generator=g),
+                                  torch.randint(0, W + 1, (n,), generator=g), torch.randint(0, H + 1, (n,), generator=g)],
+                                 1).to(dev))
+    outs = ops.regress_batch(mid_w, fine_w, pyr1, pyr2, props)
+    for i in range(len(sizes)):
+        single = ops.regress(mid_w, fine_w, pyr1[i], pyr2[i], props[i])
+        for k in ("matches1", "probs1", "matches2", "probs2"):
+            assert torch.equal(outs[i][k], single[k]), (i, k)

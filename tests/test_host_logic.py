@@ -1,0 +1,60 @@
+"""Host-side pieces of the product path that need no GPU: filter_coarse semantics against the
+oracle (which is pinned to the reference), image sizing, checkpoint schema."""
+import numpy as np
+import torch
+
+from oracle import p2p_oracle as orc
+from patch2pix_amd.networks.utils import filter_coarse
+from patch2pix_amd.utils import synthetic
+from patch2pix_amd.utils.datasets.preprocess import cal_rescale_size, load_im_flexible
+
+
+def test_filter_coarse_matches_oracle_including_fallbacks():
+    g = torch.Generator().manual_seed(0)
+    for trial in range(10):
+        n = 150
+        m = torch.randint(0, 5, (n, 4), generator=g) * 8 + 4
+        s = torch.rand(n, generator=g)
+        for mutual in (True, False):
+            for thres in (0.0, 0.5, 2.0):          # 2.0: nothing passes -> keep-all fallback
+                a, b = filter_coarse(m[None], s[None], thres, mutual)
+                r, rs = orc.filter_coarse(m, s, thres, mutual)
+                assert torch.equal(a[0], r) and torch.equal(b[0], rs)
+        np.random.seed(5)
+        a, _ = filter_coarse([m], [s], 0.0, True, ptmax=37)
+        r, _ = orc.filter_coarse(m, s, 0.0, True, ptmax=37, rng=np.random.RandomState(5))
+        assert torch.equal(a[0], r) and a[0].shape[0] == 37
+    # no duplicates at all + mutual -> the reference keeps every row (utils.py:48-50)
+    m = torch.arange(40).reshape(10, 4)
+    a, b = filter_coarse([m], [torch.ones(10)], 0.0, True)
+    assert torch.equal(a[0], m)
+    # coordinates too large for the packed key fall back to the generic row-unique
+    big = torch.tensor([[70000, 1, 2, 3], [70000, 1, 2, 3], [5, 1, 2, 3]])
+    a, _ = filter_coarse([big], [torch.tensor([0.3, 0.2, 0.9])], 0.0, True)
+    assert torch.equal(a[0], big[:1])
+
+
+def test_rescale_size_rounds_down_to_multiple_of_16():
+    assert cal_rescale_size(640, 640, 480, k_size=2, scale_factor=1 / 8) == (640, 480)
+    assert cal_rescale_size(1024, 1600, 1200, k_size=2, scale_factor=1 / 8) == (1024, 768)
+    assert cal_rescale_size(400, 400, 300, k_size=2, scale_factor=1 / 8) == (400, 288)
+
+
+def test_load_im_flexible(tmp_path):
+    from PIL import Image
+    im1, _ = synthetic.make_image_pair(3, 150, 203)
+    Image.fromarray(im1).save(tmp_path / "a.png")
+    t, scale = load_im_flexible(str(tmp_path / "a.png"), 2, 8, imsize=None)
+    assert t.shape == (3, 144, 192) and t.dtype == torch.float32
+    assert scale == (203 / 192, 150 / 144)
+    t2, _ = load_im_flexible(str(tmp_path / "a.png"), 2, 8, imsize=4096)      # never up-sample
+    assert t2.shape == t.shape
+
+
+def test_synthetic_checkpoint_has_reference_schema():
+    ck = synthetic.make_checkpoint(1, backbone=False)
+    assert {"backbone", "feat_idx", "change_stride", "regressor_config", "state_dict"} <= set(ck)
+    sd = ck["state_dict"]
+    assert tuple(sd["ncn.conv.0.weight"].shape) == (3, 16, 1, 3, 3, 3)
+    assert tuple(sd["regress_fine.conv.0.weight"].shape) == (512, 518, 3, 3)
+    assert ck["regressor_config"].psize == [16, 16]
