@@ -99,9 +99,23 @@ def main():
     np.random.seed(1234 + rank)
     from patch2pix_amd.gather import gather_matches
 
-    def step(i):
+    def submit(i):
         f1, f2 = batches[i % nbatches]
-        return net.predict_fine_from_feats(f1, f2, ksize=KSIZE, ncn_thres=0.0, mutual=True, ptmax=PTMAX)
+        return net.coarse_async(f1, f2, ksize=KSIZE)
+
+    def finish(ticket):
+        return net.fine_from_ticket(ticket, ncn_thres=0.0, mutual=True, ptmax=PTMAX)
+
+    def run(nsteps):
+        """nsteps steps, software-pipelined on one stream: the coarse stage of step i+1 is enqueued
+        before the host filters step i, so the GPU never waits for the host."""
+        out = []
+        ticket = submit(0)
+        for i in range(nsteps):
+            nxt = submit(i + 1) if i + 1 < nsteps else None
+            out.append(finish(ticket))
+            ticket = nxt
+        return out
 
     def barrier():
         if dist is not None:
@@ -109,12 +123,11 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
-        for i in range(args.warmup):
-            step(i)
+        run(args.warmup)
         barrier()
         ops.regress_events = []
         t0 = time.perf_counter()
-        results = [step(i) for i in range(args.steps)]
+        results = run(args.steps)
         # final gather of the match arrays (the only inter-GPU exchange of the path)
         rows, ids = [], []
         for i, (fine, score, coarse) in enumerate(results):

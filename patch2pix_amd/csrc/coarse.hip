@@ -302,6 +302,19 @@ __global__ __launch_bounds__(256) void nc_layer2_kernel(const float *__restrict_
 #pragma unroll
     for (int i = 0; i < 8; ++i) out[i] = 0.f;
 
+    // source offset of every staged row (identical for all 32 channels): computed once
+    int *rowoff = (int *)(tile2 + nrows * t.rs);
+    for (int r = tid; r < nrows; r += 256) {
+        const int dc = r % hc, db = (r / hc) % hb, da = r / (hc * hb);
+        const int ia = a + da - 1, ib = b0 + db - 1, ic = c0 + dc - 1;
+        const bool rok = ia >= 0 && ia < v.d0 && ib >= 0 && ib < v.d1 && ic >= 0 && ic < v.d2;
+        rowoff[r] = rok ? ((ia * v.d1 + ib) * v.d2 + ic) * v.d3 : -1;
+    }
+    const int colid = d0 + lane - 1;
+    const bool colok = lane < ncol && colid >= 0 && colid < v.d3;
+    const int slab_c = t.rs, slab_b = hc * t.rs, slab_a = hb * hc * t.rs;
+    const float *mybase = tile2 + (rb * hc + rc) * t.rs + 8 * rr;
+
     for (int branch = 0; branch < 2; ++branch) {
         float acc[8];
 #pragma unroll
@@ -309,15 +322,20 @@ __global__ __launch_bounds__(256) void nc_layer2_kernel(const float *__restrict_
         for (int ch = 0; ch < 16; ++ch) {
             const float *src = H1 + (size_t)(branch * 16 + ch) * nAB;
             __syncthreads();
-            // stage one channel: each wave copies whole rows (coalesced along the last axis)
-            for (int r = wave; r < nrows; r += 4) {
-                const int dc = r % hc, db = (r / hc) % hb, da = r / (hc * hb);
-                const int ia = a + da - 1, ib = b0 + db - 1, ic = c0 + dc - 1;
-                const bool rok = ia >= 0 && ia < v.d0 && ib >= 0 && ib < v.d1 && ic >= 0 && ic < v.d2;
-                const float *row = src + ((size_t)(ia * v.d1 + ib) * v.d2 + ic) * v.d3;
-                for (int col = lane; col < ncol; col += 64) {
-                    const int id = d0 + col - 1;
-                    tile2[r * t.rs + col] = (rok && id >= 0 && id < v.d3) ? row[id] : 0.f;
+            // stage one channel: each wave copies whole rows (coalesced along the last axis), eight
+            // rows in flight per wave so that the loads overlap
+            for (int r0 = wave; r0 < nrows; r0 += 32) {
+                float vals[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = r0 + 4 * u;
+                    const int off = (r < nrows) ? rowoff[r] : -1;
+                    vals[u] = (off >= 0 && colok) ? src[off + colid] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = r0 + 4 * u;
+                    if (r < nrows && lane < ncol) tile2[r * t.rs + lane] = vals[u];
                 }
             }
             __syncthreads();
@@ -327,7 +345,7 @@ __global__ __launch_bounds__(256) void nc_layer2_kernel(const float *__restrict_
                     for (int db = 0; db < 3; ++db) {
 #pragma unroll
                         for (int dc = 0; dc < 3; ++dc) {
-                            const float *p = tile2 + ((da * hb + rb + db) * hc + rc + dc) * t.rs + 8 * rr;
+                            const float *p = mybase + da * slab_a + db * slab_b + dc * slab_c;
                             const f32x4 x0 = *(const f32x4 *)p, x1 = *(const f32x4 *)(p + 4);
                             const float x8 = p[8], x9 = p[9];
                             const float x[10] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3], x8, x9};
@@ -360,13 +378,13 @@ __global__ __launch_bounds__(256) void nc_layer2_kernel(const float *__restrict_
 static NcTile pick_nc_tile(const Vol &v) {
     NcTile best{4, 8, 4, 36};
     double best_eff = -1;
-    const int tbs[] = {2, 3, 4, 5, 6, 8}, tcs[] = {4, 5, 6, 8, 10, 12, 15, 16}, tdrs[] = {2, 3, 4, 5, 6, 8};
+    const int tbs[] = {2, 3, 4, 5, 6, 8}, tcs[] = {4, 5, 6, 8, 10, 12, 15, 16}, tdrs[] = {2, 3, 4, 5, 6, 7};   // 8*tdr+2 columns must fit one wave
     for (int tdr : tdrs)
         for (int tb : tbs)
             for (int tc : tcs) {
                 if (tb * tc * tdr > 256) continue;
                 const int rs = 8 * tdr + 4;
-                const size_t lds = (size_t)3 * (tb + 2) * (tc + 2) * rs * 4;
+                const size_t lds = (size_t)3 * (tb + 2) * (tc + 2) * (rs + 1) * 4;
                 if (lds > 52 * 1024) continue;
                 const double groups = (double)v.d0 * ceil_div(v.d1, tb) * ceil_div(v.d2, tc) * ceil_div(v.d3, 8 * tdr);
                 const double useful = (double)v.d0 * v.d1 * v.d2 * v.d3;
@@ -593,7 +611,7 @@ extern "C" int p2p_coarse_forward(const float *featA, const float *featB, int C,
     hipLaunchKernelGGL(nc_layer1_kernel, dim3(ntiles), dim3(256), 0, stream, P, v, rkey1, ckey1, ncn->w1cat, ncn->b1cat, H1);
     const NcTile nt = pick_nc_tile(v);
     const int ntiles2 = v.d0 * ceil_div(v.d1, nt.tb) * ceil_div(v.d2, nt.tc) * ceil_div(v.d3, 8 * nt.tdr);
-    const size_t lds2 = (size_t)3 * (nt.tb + 2) * (nt.tc + 2) * nt.rs * 4;
+    const size_t lds2 = (size_t)3 * (nt.tb + 2) * (nt.tc + 2) * (nt.rs + 1) * 4;
     hipLaunchKernelGGL(nc_layer2_kernel, dim3(ntiles2), dim3(256), lds2, stream, H1, v, nt, ncn->w2cat, ncn->b2, Y);
     hipLaunchKernelGGL(rowcolmax_kernel, mgrid, dim3(256), 0, stream, Y, nAc, nBc, rkey2, ckey2);
     const size_t nel = (size_t)nAc * nBc;

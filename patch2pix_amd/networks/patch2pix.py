@@ -128,6 +128,7 @@ class Patch2Pix(nn.Module):
             self.regress_fine = self.regress_mid if self.shared else _Holder(_regressor_spec(rc.feat_dim))
         self.to(self.device)
         self._packed = None
+        self._copy_stream = None
         self.init_weights_(weights_dict=config.weights_dict)
         self.eval()
 
@@ -256,19 +257,45 @@ class Patch2Pix(nn.Module):
                                                                upsample=self.upsample, center=center)
         return filter_coarse(coarse_matches, match_scores, ncn_thres, mutual)
 
+    def coarse_async(self, feats1, feats2, ksize=2):
+        """Enqueue the coarse stage of a batch and an asynchronous device-to-host copy of its
+        (small) match arrays on a side stream; returns a ticket for `fine_from_ticket`.  Lets a
+        caller enqueue the next batch's coarse stage before it filters the current one on the host,
+        so that the host-side filter_coarse (reference networks/utils.py:38-72) never idles the GPU."""
+        corr4d, delta4d = self.forward_coarse_match(feats1[-1], feats2[-1], ksize=ksize)
+        matches_, score_ = self.cal_coarse_matches(corr4d, delta4d, ksize=ksize, upsample=self.upsample, center=True)
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        host_m = torch.empty(matches_.shape, dtype=matches_.dtype, pin_memory=True)
+        host_s = torch.empty(score_.shape, dtype=score_.dtype, pin_memory=True)
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(ready)
+            host_m.copy_(matches_, non_blocking=True)
+            host_s.copy_(score_, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self._copy_stream)
+        return dict(feats1=feats1, feats2=feats2, matches=matches_, scores=score_, host=(host_m, host_s), done=done)
+
+    def fine_from_ticket(self, ticket, ncn_thres=0.0, mutual=True, return_all=False, ptmax=None):
+        ticket["done"].synchronize()
+        host_m, host_s = ticket["host"]
+        coarse_matches, match_scores = filter_coarse(ticket["matches"], ticket["scores"], ncn_thres, mutual, ptmax=ptmax,
+                                                     host_copy=(host_m.numpy(), host_s.numpy()))
+        coarse_matches = self.shift_to_anchors(coarse_matches)
+        fine, fine_scores, mid, mid_scores = self._fine_chain(ticket["feats1"], ticket["feats2"], coarse_matches)
+        if return_all:
+            return fine, fine_scores, mid, mid_scores, coarse_matches
+        return fine, fine_scores, coarse_matches
+
     def predict_fine_from_feats(self, feats1, feats2, ksize=2, ncn_thres=0.0, mutual=True, return_all=False,
                                 ptmax=None):
         """predict_fine after the backbone: the part of the path that is HIP end to end.
         `ptmax` (opt-in, training semantics of utils.py:55-63) caps/tiles the proposals."""
-        corr4d, delta4d = self.forward_coarse_match(feats1[-1], feats2[-1], ksize=ksize)
-        coarse_matches, match_scores = self.cal_coarse_matches(corr4d, delta4d, ksize=ksize,
-                                                               upsample=self.upsample, center=True)
-        coarse_matches, match_scores = filter_coarse(coarse_matches, match_scores, ncn_thres, mutual, ptmax=ptmax)
-        coarse_matches = self.shift_to_anchors(coarse_matches)
-        fine, fine_scores, mid, mid_scores = self._fine_chain(feats1, feats2, coarse_matches)
-        if return_all:
-            return fine, fine_scores, mid, mid_scores, coarse_matches
-        return fine, fine_scores, coarse_matches
+        ticket = self.coarse_async(feats1, feats2, ksize)
+        return self.fine_from_ticket(ticket, ncn_thres, mutual, return_all, ptmax)
 
     def predict_fine(self, im1, im2, ksize=2, ncn_thres=0.0, mutual=True, return_all=False):
         feats1 = self.extract.pyramid(im1)

@@ -24,8 +24,13 @@ def _unique_rows(rows):
     return first, counts
 
 
-def filter_coarse(coarse_matches, match_scores, ncn_thres=0.0, mutual=True, ptmax=None):
-    if isinstance(coarse_matches, torch.Tensor):
+def filter_coarse(coarse_matches, match_scores, ncn_thres=0.0, mutual=True, ptmax=None, host_copy=None):
+    """`host_copy=(rows_np, scores_np)` supplies an already transferred copy of the two arrays
+    (see Patch2Pix.coarse_async), skipping the synchronous device-to-host copy."""
+    if host_copy is not None:
+        device = coarse_matches.device
+        host_rows, host_scores = host_copy
+    elif isinstance(coarse_matches, torch.Tensor):
         device = coarse_matches.device
         host_rows = coarse_matches.detach().cpu().numpy()
         host_scores = match_scores.detach().cpu().numpy()
