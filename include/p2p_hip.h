@@ -69,6 +69,19 @@ typedef struct p2p_regressor_params {
 int p2p_regressor_create(const p2p_regressor_params *params, p2p_regressor **out);
 void p2p_regressor_destroy(p2p_regressor *reg);
 
+/* Arithmetic used for the two convolutions of a regressor (everything else is fp32 either way):
+ *   P2P_REGRESS_F32    v_mfma_f32_32x32x2_f32, bit-identical to an fp32 fma chain;
+ *   P2P_REGRESS_BF16X2 every fp32 operand split into two bf16 (16 significant bits), three
+ *                      v_mfma_f32_32x32x16_bf16 per product, fp32 accumulation: 5.3x the matrix-core
+ *                      rate, regressed coordinates within ~2e-4 px of the fp32 evaluation.
+ * New handles start in the mode named by the environment variable P2P_REGRESS_MODE ("f32" |
+ * "bf16x2"), else P2P_REGRESS_DEFAULT.                                                          */
+#define P2P_REGRESS_F32     0
+#define P2P_REGRESS_BF16X2  1
+#define P2P_REGRESS_DEFAULT P2P_REGRESS_F32
+int p2p_regressor_set_mode(p2p_regressor *reg, int mode);
+int p2p_regressor_get_mode(const p2p_regressor *reg);
+
 /* ---- coarse stage ---------------------------------------------------------------------------- */
 
 /* Workspace (bytes) p2p_coarse_forward needs for these sizes. */

@@ -18,14 +18,15 @@
 //     time in exact consumption order: one global_load_dwordx4 per lane feeds four k-steps;
 //   * fp32 MFMA is bit-identical to an fma chain, so results match an fp32 CPU evaluation to
 //     round-off of the (fixed, documented) summation order: taps outer, channels inner.
-#include "p2p_common.h"
+#include "regress_common.h"
 
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace p2p {
 
-constexpr int NT = 512;                 // threads per workgroup (8 waves)
 constexpr int K1_CHUNKS_PER_TAP = 65;   // 1 (level-0 of both images, 6 ch padded to 8) + 2*(8+8+16)
 constexpr int K1_CHUNKS = 9 * K1_CHUNKS_PER_TAP;
 constexpr int K2_CHUNKS_PER_TAP = 64;   // 512 channels / 8
@@ -33,7 +34,7 @@ constexpr int K2_CHUNKS = 9 * K2_CHUNKS_PER_TAP;
 constexpr int PF = 2;                   // weight prefetch distance (chunks); buffers are padded by PF chunks
 constexpr int WP1_FLOATS = 8 * (K1_CHUNKS + PF) * 2 * 64 * 4;
 constexpr int WP2_FLOATS = 8 * (K2_CHUNKS + PF) * 2 * 64 * 4;
-constexpr int MAXB = 8;                 // image pairs per launch
+
 
 // LDS carve-up (floats)
 constexpr int TILE_L0 = 0, TILE_L1 = 768, TILE_L2 = 5952, TILE_L3 = 7552, TILE_IMG = 8704;
@@ -46,28 +47,6 @@ constexpr int LDS_F2 = LDS_F1 + 512;              // [256]
 constexpr int LDS_MISC = LDS_F2 + 256;            // [16] raw outputs / current proposal
 constexpr int LDS_FLOATS = LDS_MISC + 16;
 constexpr size_t LDS_BYTES = size_t(LDS_FLOATS) * 4;
-
-struct RegDev {
-    const float *wp1, *wp2, *bn1s, *bn1b, *bn2s, *bn2b;
-    const float *fc1t, *fc1b, *bnf1s, *bnf1b, *fc2t, *fc2b, *bnf2s, *bnf2b, *fc3, *fc3b;
-};
-
-struct ItemDev {
-    const float *pyr[2][4];
-    int H[2], W[2];
-};
-
-struct RegressArgs {
-    ItemDev item[MAXB];
-    int start[MAXB + 1];          // proposal range of each item in the concatenated arrays
-    int nitems;
-    const void *proposals;
-    int is_float, n, nlevels;
-    RegDev reg[2];
-    float *matches[2], *probs[2], *raw[2];
-};
-
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -144,19 +123,13 @@ __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
         }
         __syncthreads();
 
-        // cell index of patch row/col `p` (0..15) at level j, relative to the tile origin
-        auto cell = [&](int origin, int p, int j, int dim) -> int {
-            const int d = dim >> j;
-            return clampi((origin + p) >> j, 0, d - 1) - clampi(origin >> j, 0, d - 1);
-        };
-
         // ---------------------------------------------------------------- per-pixel L2 scale
         {
             const int img = tid >> 8, pix = tid & 255, py = pix >> 4, px = pix & 15;
             const float *t = tiles + img * TILE_IMG;
             float ss = 0.f;
             {
-                const float *p = t + TILE_L0 + cell(y0[img], py, 0, I.H[img]) * 16 + cell(x0[img], px, 0, I.W[img]);
+                const float *p = t + TILE_L0 + patch_cell(y0[img], py, 0, I.H[img]) * 16 + patch_cell(x0[img], px, 0, I.W[img]);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { float v = p[c * 256]; ss = fmaf(v, v, ss); }
             }
@@ -165,7 +138,7 @@ __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
                 const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
                 const int Cc = (j == 3) ? 128 : 64;
                 const int off = (j == 1) ? TILE_L1 : (j == 2) ? TILE_L2 : TILE_L3;
-                const float *p = t + off + cell(y0[img], py, j, I.H[img]) * Rr + cell(x0[img], px, j, I.W[img]);
+                const float *p = t + off + patch_cell(y0[img], py, j, I.H[img]) * Rr + patch_cell(x0[img], px, j, I.W[img]);
                 for (int c = 0; c < Cc; ++c) { float v = p[c * Rr * Rr]; ss = fmaf(v, v, ss); }
             }
             scale[tid] = 1.0f / sqrtf(ss + 1e-6f);
@@ -201,10 +174,10 @@ __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
                         const int pofs = pyc[t] * 16 + pxc[t];
                         const float s0 = ok[t] ? scale[pofs] : 0.f;
                         const float s1 = ok[t] ? scale[256 + pofs] : 0.f;
-                        const float *t0 = tiles + TILE_L0 + cell(y0[0], pyc[t], 0, I.H[0]) * 16 +
-                                          cell(x0[0], pxc[t], 0, I.W[0]);
-                        const float *t1 = tiles + TILE_IMG + TILE_L0 + cell(y0[1], pyc[t], 0, I.H[1]) * 16 +
-                                          cell(x0[1], pxc[t], 0, I.W[1]);
+                        const float *t0 = tiles + TILE_L0 + patch_cell(y0[0], pyc[t], 0, I.H[0]) * 16 +
+                                          patch_cell(x0[0], pxc[t], 0, I.W[0]);
+                        const float *t1 = tiles + TILE_IMG + TILE_L0 + patch_cell(y0[1], pyc[t], 0, I.H[1]) * 16 +
+                                          patch_cell(x0[1], pxc[t], 0, I.W[1]);
                         float v0 = t0[half * 256] * s0;                                   // img0 c0 | c1
                         float v1 = half ? t1[0] * s1 : t0[512] * s0;                      // img0 c2 | img1 c0
                         float v2 = t1[(1 + half) * 256] * s1;                             // img1 c1 | c2
@@ -225,10 +198,10 @@ __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
                         const int nchunk = (j == 3) ? 16 : 8;
                         const int off = (j == 1) ? TILE_L1 : (j == 2) ? TILE_L2 : TILE_L3;
                         const float *base = tiles + img * TILE_IMG + off + half * CS;
-                        const float *p0 = base + cell(y0[img], pyc[0], j, I.H[img]) * Rr +
-                                          cell(x0[img], pxc[0], j, I.W[img]);
-                        const float *p1 = base + cell(y0[img], pyc[1], j, I.H[img]) * Rr +
-                                          cell(x0[img], pxc[1], j, I.W[img]);
+                        const float *p0 = base + patch_cell(y0[img], pyc[0], j, I.H[img]) * Rr +
+                                          patch_cell(x0[img], pxc[0], j, I.W[img]);
+                        const float *p1 = base + patch_cell(y0[img], pyc[1], j, I.H[img]) * Rr +
+                                          patch_cell(x0[img], pxc[1], j, I.W[img]);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) { a0[q] = p0[2 * q * CS] * s0; a1[q] = p1[2 * q * CS] * s1; }
                         for (int ch = 0; ch < nchunk; ++ch) {
@@ -336,57 +309,8 @@ __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
         }
         __syncthreads();
 
-        // ---------------------------------------------------------------- FC tail (modules.py:89-99)
-        {
-            const f32x4 *w = (const f32x4 *)R.fc1t + tid;
-            float s = 0.f;
-#pragma unroll 8
-            for (int kq = 0; kq < 128; ++kq) {
-                f32x4 wv = w[kq * 512];
-                s = fmaf(wv[0], V[4 * kq + 0], s);
-                s = fmaf(wv[1], V[4 * kq + 1], s);
-                s = fmaf(wv[2], V[4 * kq + 2], s);
-                s = fmaf(wv[3], V[4 * kq + 3], s);
-            }
-            s += R.fc1b[tid];
-            F1[tid] = fmaxf(fmaf(s, R.bnf1s[tid], R.bnf1b[tid]), 0.f);
-        }
-        __syncthreads();
-        if (tid < 256) {
-            const f32x4 *w = (const f32x4 *)R.fc2t + tid;
-            float s = 0.f;
-#pragma unroll 8
-            for (int kq = 0; kq < 128; ++kq) {
-                f32x4 wv = w[kq * 256];
-                s = fmaf(wv[0], F1[4 * kq + 0], s);
-                s = fmaf(wv[1], F1[4 * kq + 1], s);
-                s = fmaf(wv[2], F1[4 * kq + 2], s);
-                s = fmaf(wv[3], F1[4 * kq + 3], s);
-            }
-            s += R.fc2b[tid];
-            F2[tid] = fmaxf(fmaf(s, R.bnf2s[tid], R.bnf2b[tid]), 0.f);
-        }
-        __syncthreads();
-        if (tid < 5) {
-            const float *w = R.fc3 + tid * 256;
-            float s = 0.f;
-            for (int k = 0; k < 256; ++k) s = fmaf(w[k], F2[k], s);
-            s += R.fc3b[tid];
-            misc[tid] = s;
-            if (args.raw[lvl]) args.raw[lvl][(size_t)prop * 5 + tid] = s;
-            // parse_regressor_out (patch2pix.py:138-155), psize 16, ptype 'center'
-            if (tid < 4) {
-                const float off = 16.0f * tanhf(fmaxf(s, 0.f)) - 8.0f;
-                float fm = misc[8 + tid] + off;
-                const float hi = (float)((tid & 1) ? I.H[tid >> 1] : I.W[tid >> 1]);
-                fm = fminf(fmaxf(fm, 0.f), hi);
-                if (args.matches[lvl]) args.matches[lvl][(size_t)prop * 4 + tid] = fm;
-                misc[8 + tid] = fm;       // becomes the next level's proposal (un-truncated)
-            } else {
-                if (args.probs[lvl]) args.probs[lvl][prop] = 1.0f / (1.0f + expf(-s));
-            }
-        }
-        __syncthreads();
+        // ---------------------------------------------------------------- FC tail + parse
+        fc_tail_parse(R, I, args, lvl, prop, tid, V, F1, F2, misc);
     }
 }
 
@@ -418,6 +342,24 @@ static void fold_bn(const p2p_bn_params &bn, int n, float *scale, float *shift) 
 
 using namespace p2p;
 
+// Arithmetic of the two convolutions: the environment variable P2P_REGRESS_MODE ("f32" | "bf16x2")
+// picks the default for newly created regressors; p2p_regressor_set_mode overrides it per handle.
+static int default_regress_mode() {
+    const char *e = std::getenv("P2P_REGRESS_MODE");
+    if (e && std::strcmp(e, "f32") == 0) return P2P_REGRESS_F32;
+    if (e && std::strcmp(e, "bf16x2") == 0) return P2P_REGRESS_BF16X2;
+    return P2P_REGRESS_DEFAULT;
+}
+
+extern "C" int p2p_regressor_set_mode(p2p_regressor *reg, int mode) {
+    P2P_REQUIRE(reg, P2P_EINVAL, "p2p_regressor_set_mode: null handle");
+    P2P_REQUIRE(mode == P2P_REGRESS_F32 || mode == P2P_REGRESS_BF16X2, P2P_EINVAL, "p2p_regressor_set_mode: unknown mode %d", mode);
+    reg->mode = mode;
+    return P2P_OK;
+}
+
+extern "C" int p2p_regressor_get_mode(const p2p_regressor *reg) { return reg ? reg->mode : P2P_EINVAL; }
+
 extern "C" int p2p_regressor_create(const p2p_regressor_params *p, p2p_regressor **out) {
     P2P_REQUIRE(p && out, P2P_EINVAL, "p2p_regressor_create: null argument");
     const float *const need[] = {p->conv1_w, p->conv2_w, p->fc1_w, p->fc1_b, p->fc2_w, p->fc2_b, p->fc3_w, p->fc3_b,
@@ -431,6 +373,7 @@ extern "C" int p2p_regressor_create(const p2p_regressor_params *p, p2p_regressor
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += (n + 63) & ~size_t(63); return o; };
     const size_t o_wp1 = take(WP1_FLOATS), o_wp2 = take(WP2_FLOATS);
+    const size_t o_ws1 = take(WS1_FLOATS), o_ws2 = take(WS2_FLOATS);
     const size_t o_bn1s = take(512), o_bn1b = take(512), o_bn2s = take(512), o_bn2b = take(512);
     const size_t o_fc1t = take(512 * 512), o_fc1b = take(512), o_bnf1s = take(512), o_bnf1b = take(512);
     const size_t o_fc2t = take(256 * 512), o_fc2b = take(256), o_bnf2s = take(256), o_bnf2b = take(256);
@@ -464,6 +407,7 @@ extern "C" int p2p_regressor_create(const p2p_regressor_params *p, p2p_regressor
                         h[dst] = p->conv2_w[((size_t)n * 512 + ch) * 9 + tap];
                     }
         }
+    pack_split_weights(p->conv1_w, p->conv2_w, &h[o_ws1], &h[o_ws2]);
     fold_bn(p->bn1, 512, &h[o_bn1s], &h[o_bn1b]);
     fold_bn(p->bn2, 512, &h[o_bn2s], &h[o_bn2b]);
     fold_bn(p->bnf1, 512, &h[o_bnf1s], &h[o_bnf1b]);
@@ -489,6 +433,8 @@ extern "C" int p2p_regressor_create(const p2p_regressor_params *p, p2p_regressor
     p2p_regressor *r = new p2p_regressor();
     r->dev = dev;
     r->wp1 = dev + o_wp1; r->wp2 = dev + o_wp2;
+    r->ws1 = dev + o_ws1; r->ws2 = dev + o_ws2;
+    r->mode = default_regress_mode();
     r->bn1s = dev + o_bn1s; r->bn1b = dev + o_bn1b; r->bn2s = dev + o_bn2s; r->bn2b = dev + o_bn2b;
     r->fc1t = dev + o_fc1t; r->fc1b = dev + o_fc1b; r->bnf1s = dev + o_bnf1s; r->bnf1b = dev + o_bnf1b;
     r->fc2t = dev + o_fc2t; r->fc2b = dev + o_fc2b; r->bnf2s = dev + o_bnf2s; r->bnf2b = dev + o_bnf2b;
@@ -505,7 +451,7 @@ extern "C" void p2p_regressor_destroy(p2p_regressor *reg) {
 
 static RegDev to_dev(const p2p_regressor *r) {
     RegDev d;
-    d.wp1 = r->wp1; d.wp2 = r->wp2; d.bn1s = r->bn1s; d.bn1b = r->bn1b; d.bn2s = r->bn2s; d.bn2b = r->bn2b;
+    d.wp1 = r->wp1; d.wp2 = r->wp2; d.ws1 = r->ws1; d.ws2 = r->ws2; d.bn1s = r->bn1s; d.bn1b = r->bn1b; d.bn2s = r->bn2s; d.bn2b = r->bn2b;
     d.fc1t = r->fc1t; d.fc1b = r->fc1b; d.bnf1s = r->bnf1s; d.bnf1b = r->bnf1b;
     d.fc2t = r->fc2t; d.fc2b = r->fc2b; d.bnf2s = r->bnf2s; d.bnf2b = r->bnf2b; d.fc3 = r->fc3; d.fc3b = r->fc3b;
     return d;
@@ -527,6 +473,7 @@ extern "C" int p2p_regress_batch(const p2p_regressor *reg1, const p2p_regressor 
     P2P_REQUIRE(total < (1ll << 31), P2P_EINVAL, "p2p_regress: too many proposals");
     P2P_REQUIRE(proposals, P2P_EINVAL, "p2p_regress: null proposals");
     P2P_REQUIRE(reg2 ? (matches2 && probs2) : (matches1 && probs1), P2P_EINVAL, "p2p_regress: missing output buffers");
+    P2P_REQUIRE(!reg2 || reg2->mode == reg1->mode, P2P_EINVAL, "p2p_regress: the two regressors use different arithmetic modes");
     for (int i = 0; i < nitems; ++i) {
         const p2p_pyramid *im[2] = {im1 + i, im2 + i};
         for (int s = 0; s < 2; ++s) {
@@ -572,8 +519,13 @@ extern "C" int p2p_regress_batch(const p2p_regressor *reg1, const p2p_regressor 
         a.matches[0] = adv(matches1, 4); a.probs[0] = adv(probs1, 1); a.raw[0] = adv(raw1, 5);
         a.matches[1] = adv(matches2, 4); a.probs[1] = adv(probs2, 1); a.raw[1] = adv(raw2, 5);
         if (n > 0) {
-            hipLaunchKernelGGL(regress_kernel, dim3(n), dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
-            const int st = check_launch("regress_kernel");
+            int st;
+            if (reg1->mode == P2P_REGRESS_BF16X2) {
+                st = launch_regress_split(a, n, (hipStream_t)stream);
+            } else {
+                hipLaunchKernelGGL(regress_kernel, dim3(n), dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+                st = check_launch("regress_kernel");
+            }
             if (st != P2P_OK) return st;
         }
         first_prop += n;

@@ -1,0 +1,107 @@
+// Pieces shared by the two fine-stage kernels (exact-f32 MFMA and split-bf16 MFMA).
+#pragma once
+#include "p2p_common.h"
+
+namespace p2p {
+
+constexpr int NT = 512;                 // threads per workgroup (8 waves)
+constexpr int MAXB = 8;                 // image pairs per launch
+
+struct RegDev {
+    const float *wp1, *wp2;             // f32 MFMA-fragment order (regress.hip)
+    const float *ws1, *ws2;             // split-bf16 fragment order (regress_split.hip), viewed as 16-byte units
+    const float *bn1s, *bn1b, *bn2s, *bn2b;
+    const float *fc1t, *fc1b, *bnf1s, *bnf1b, *fc2t, *fc2b, *bnf2s, *bnf2b, *fc3, *fc3b;
+};
+
+struct ItemDev {
+    const float *pyr[2][4];
+    int H[2], W[2];
+};
+
+struct RegressArgs {
+    ItemDev item[MAXB];
+    int start[MAXB + 1];          // proposal range of each item in the concatenated arrays
+    int nitems;
+    const void *proposals;
+    int is_float, n, nlevels;
+    RegDev reg[2];
+    float *matches[2], *probs[2], *raw[2];
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// cell index of patch row/col `p` (0..15) at pyramid level j, relative to the staged tile's origin:
+// clamp(floor((origin+p)/2^j), 0, dim/2^j - 1) - clamp(floor(origin/2^j), ...)   (networks/utils.py:22-23)
+__device__ __forceinline__ int patch_cell(int origin, int p, int j, int dim) {
+    const int d = dim >> j;
+    return clampi((origin + p) >> j, 0, d - 1) - clampi(origin >> j, 0, d - 1);
+}
+
+// FC 512->512->256->5 with folded BatchNorm1d + ReLU (networks/modules.py:89-99), then
+// parse_regressor_out (networks/patch2pix.py:138-155; psize 16, ptype 'center').
+// V: pooled conv features [512] in LDS; F1/F2 scratch [512]/[256]; misc[0..4] raw outputs,
+// misc[8..11] current proposal (in: base of the offsets, out: regressed match).
+__device__ __forceinline__ void fc_tail_parse(const RegDev &R, const ItemDev &I, const RegressArgs &args, int lvl, int prop,
+                                              int tid, const float *V, float *F1, float *F2, float *misc) {
+    {
+        const f32x4 *w = (const f32x4 *)R.fc1t + tid;
+        float s = 0.f;
+#pragma unroll 8
+        for (int kq = 0; kq < 128; ++kq) {
+            f32x4 wv = w[kq * 512];
+            s = fmaf(wv[0], V[4 * kq + 0], s);
+            s = fmaf(wv[1], V[4 * kq + 1], s);
+            s = fmaf(wv[2], V[4 * kq + 2], s);
+            s = fmaf(wv[3], V[4 * kq + 3], s);
+        }
+        s += R.fc1b[tid];
+        F1[tid] = fmaxf(fmaf(s, R.bnf1s[tid], R.bnf1b[tid]), 0.f);
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const f32x4 *w = (const f32x4 *)R.fc2t + tid;
+        float s = 0.f;
+#pragma unroll 8
+        for (int kq = 0; kq < 128; ++kq) {
+            f32x4 wv = w[kq * 256];
+            s = fmaf(wv[0], F1[4 * kq + 0], s);
+            s = fmaf(wv[1], F1[4 * kq + 1], s);
+            s = fmaf(wv[2], F1[4 * kq + 2], s);
+            s = fmaf(wv[3], F1[4 * kq + 3], s);
+        }
+        s += R.fc2b[tid];
+        F2[tid] = fmaxf(fmaf(s, R.bnf2s[tid], R.bnf2b[tid]), 0.f);
+    }
+    __syncthreads();
+    if (tid < 5) {
+        const float *w = R.fc3 + tid * 256;
+        float s = 0.f;
+        for (int k = 0; k < 256; ++k) s = fmaf(w[k], F2[k], s);
+        s += R.fc3b[tid];
+        misc[tid] = s;
+        if (args.raw[lvl]) args.raw[lvl][(size_t)prop * 5 + tid] = s;
+        if (tid < 4) {
+            const float off = 16.0f * tanhf(fmaxf(s, 0.f)) - 8.0f;
+            float fm = misc[8 + tid] + off;
+            const float hi = (float)((tid & 1) ? I.H[tid >> 1] : I.W[tid >> 1]);
+            fm = fminf(fmaxf(fm, 0.f), hi);
+            if (args.matches[lvl]) args.matches[lvl][(size_t)prop * 4 + tid] = fm;
+            misc[8 + tid] = fm;       // becomes the next level's proposal (un-truncated)
+        } else {
+            if (args.probs[lvl]) args.probs[lvl][prop] = 1.0f / (1.0f + expf(-s));
+        }
+    }
+    __syncthreads();
+}
+
+// regress_split.hip
+constexpr int S1_SLABS = 9 * 2 * 17;    // conv1: per (tap, image): 1 + 4 + 4 + 8 slabs of 16 channels
+constexpr int S2_SLABS = 9 * 32;        // conv2: 512 channels / 16 per tap
+constexpr int SPF = 2;                  // weight prefetch distance in slabs (buffers padded accordingly)
+constexpr size_t WS1_FLOATS = (size_t)8 * (S1_SLABS + SPF) * 1024;   // 4 KiB per (wave, slab)
+constexpr size_t WS2_FLOATS = (size_t)8 * (S2_SLABS + SPF) * 1024;
+void pack_split_weights(const float *conv1_w, const float *conv2_w, float *ws1, float *ws2);   // host
+int launch_regress_split(const RegressArgs &a, int n, hipStream_t stream);
+
+}  // namespace p2p
