@@ -78,7 +78,7 @@ void p2p_regressor_destroy(p2p_regressor *reg);
  * "bf16x2"), else P2P_REGRESS_DEFAULT.                                                          */
 #define P2P_REGRESS_F32     0
 #define P2P_REGRESS_BF16X2  1
-#define P2P_REGRESS_DEFAULT P2P_REGRESS_F32
+#define P2P_REGRESS_DEFAULT P2P_REGRESS_BF16X2
 int p2p_regressor_set_mode(p2p_regressor *reg, int mode);
 int p2p_regressor_get_mode(const p2p_regressor *reg);
 

@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  (must be loaded first so libamdhip64.so.7 resolves to torch's copy)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libp2p_hip.so")
+LIB_PATH = os.environ.get("P2P_LIB_PATH", os.path.join(_HERE, "csrc", "libp2p_hip.so"))   # override: kernel experiments
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -17,6 +17,22 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _resource_report(text):
+    """Parse -Rpass-analysis=kernel-resource-usage remarks into {kernel: {field: value}}."""
+    report, cur = {}, None
+    for line in text.splitlines():
+        if "remark:" not in line:
+            continue
+        body = line.split("remark:", 1)[1].split("[-Rpass")[0].strip()
+        if body.startswith("Function Name:"):
+            cur = body.split(":", 1)[1].strip()
+            report[cur] = {}
+        elif cur and ":" in body:
+            k, v = body.rsplit(":", 1)
+            report[cur][k.strip()] = v.strip()
+    return report
+
+
 def build(force=False, verbose=True):
     """Compile every HIP source for gfx950 into one shared library (no torch / pybind dependency)."""
     if not force and not _stale():
@@ -26,10 +42,25 @@ def build(force=False, verbose=True):
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-               "-c", os.path.join(CSRC, src), "-o", obj]
+               "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        report = _resource_report(res.stdout)
+        other = [l for l in res.stdout.splitlines() if "-Rpass-analysis" not in l and "remark:" not in l and l.strip()
+                 and "|" not in l[:12] and not l.lstrip().startswith("^") and "__global__" not in l]
+        if other and (verbose or res.returncode):
+            print("\n".join(other), flush=True)
+        if res.returncode:
+            raise subprocess.CalledProcessError(res.returncode, cmd)
+        for name, usage in report.items():
+            if verbose:
+                print(f"    {name}: {usage.get('VGPRs', '?')} VGPR, scratch {usage.get('ScratchSize [bytes/lane]', '?')} B/lane",
+                      flush=True)
+            # Register spills are a hard error: kernels that touch scratch memory produced wrong results /
+            # memory faults on the MI355X boxes (hipcc 7.2 code objects under torch's bundled HIP 7.0 runtime).
+            if int(usage.get("ScratchSize [bytes/lane]", "0")) != 0:
+                raise RuntimeError(f"{src}: kernel {name} spills to scratch ({usage}); restructure it until it does not")
         objs.append(obj)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:

@@ -44,6 +44,7 @@ __device__ __forceinline__ int patch_cell(int origin, int p, int j, int dim) {
 // misc[8..11] current proposal (in: base of the offsets, out: regressed match).
 __device__ __forceinline__ void fc_tail_parse(const RegDev &R, const ItemDev &I, const RegressArgs &args, int lvl, int prop,
                                               int tid, const float *V, float *F1, float *F2, float *misc) {
+    asm volatile("" : "+v"(tid));      // keep the per-lane weight offsets from being hoisted out of the level loop (and spilled)
     {
         const f32x4 *w = (const f32x4 *)R.fc1t + tid;
         float s = 0.f;
@@ -84,7 +85,7 @@ __device__ __forceinline__ void fc_tail_parse(const RegDev &R, const ItemDev &I,
         if (tid < 4) {
             const float off = 16.0f * tanhf(fmaxf(s, 0.f)) - 8.0f;
             float fm = misc[8 + tid] + off;
-            const float hi = (float)((tid & 1) ? I.H[tid >> 1] : I.W[tid >> 1]);
+            const float hi = (float)((tid == 0) ? I.W[0] : (tid == 1) ? I.H[0] : (tid == 2) ? I.W[1] : I.H[1]);
             fm = fminf(fmaxf(fm, 0.f), hi);
             if (args.matches[lvl]) args.matches[lvl][(size_t)prop * 4 + tid] = fm;
             misc[8 + tid] = fm;       // becomes the next level's proposal (un-truncated)
@@ -96,10 +97,13 @@ __device__ __forceinline__ void fc_tail_parse(const RegDev &R, const ItemDev &I,
 }
 
 // regress_split.hip
-constexpr int S1_SLABS = 9 * 2 * 17;    // conv1: per (tap, image): 1 + 4 + 4 + 8 slabs of 16 channels
+constexpr int S1_SLABS = 4 + 9 * 2 * 16; // conv1: 4 slabs of level 0 (3 ch x 9 taps x 2 images, padded 54 -> 64), then per
+                                        // (tap, image) 4 + 4 + 8 slabs of 16 channels of levels 1, 2, 3
 constexpr int S2_SLABS = 9 * 32;        // conv2: 512 channels / 16 per tap
-constexpr int SPF = 2;                  // weight prefetch distance in slabs (buffers padded accordingly)
-constexpr size_t WS1_FLOATS = (size_t)8 * (S1_SLABS + SPF) * 1024;   // 4 KiB per (wave, slab)
+constexpr int SPF = 3;                  // weight prefetch distance in slabs = ring of 4 register buffers
+constexpr int S1_UNITS = 2 * S1_SLABS;   // conv1 streams one n-tile at a time: unit = (slab, n-tile), 2 KiB per (wave, unit)
+constexpr size_t WS1_FLOATS = (size_t)8 * (S1_UNITS + SPF) * 512;
+// conv2: 4 KiB per (wave, slab)
 constexpr size_t WS2_FLOATS = (size_t)8 * (S2_SLABS + SPF) * 1024;
 void pack_split_weights(const float *conv1_w, const float *conv2_w, float *ws1, float *ws2);   // host
 int launch_regress_split(const RegressArgs &a, int n, hipStream_t stream);

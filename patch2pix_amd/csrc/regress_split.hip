@@ -4,8 +4,8 @@
 // fp32 operand x represented as hi + lo (hi = bf16(x), lo = bf16(x - hi): 16 significant bits) and
 // three v_mfma_f32_32x32x16_bf16 per product:   a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi,
 // accumulated in fp32.  That is 6 matrix-core cycles per unit of K instead of 32 for the exact-f32
-// MFMA (v_mfma_f32_32x32x2_f32), at an error of ~2^-16 per product: measured against the fp64
-// oracle the regressed coordinates move by <= ~2e-4 px (bar: 1e-3 px), see tests/test_gpu_parity.py.
+// MFMA (v_mfma_f32_32x32x2_f32), at an error of ~2^-16 per product: measured against an fp64
+// evaluation the regressed coordinates move by <= ~2.5e-4 px (bar: 1e-3 px), see tests/test_gpu_parity.py.
 //
 // Differences to regress.hip that follow from the bf16 operand shape (8 consecutive K per lane):
 //   * LDS tiles are channel-innermost ([cell][C] bf16, hi and lo planes) so that a lane's A fragment
@@ -23,26 +23,34 @@ namespace p2p {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // ---- LDS layout (bytes) --------------------------------------------------------------------------
-constexpr int ST0 = 16, ST1 = 144, ST2 = 144, ST3 = 272;          // bytes per cell (C bf16 + 16 pad)
-constexpr int NC0 = 256, NC1 = 81, NC2 = 25, NC3 = 9;             // real cells; index NCj is the zero cell
-constexpr int OFF0 = 0;
-constexpr int OFF1 = OFF0 + (NC0 + 1) * ST0;                      // 4112
-constexpr int OFF2 = OFF1 + (NC1 + 1) * ST1;                      // 15920
-constexpr int OFF3 = OFF2 + (NC2 + 1) * ST2;                      // 19664
-constexpr int PLANE = 22400;                                      // >= OFF3 + (NC3+1)*ST3, multiple of 16
+// conv1 phase: levels 1-3 deduplicated tiles [img][plane][cell][C bf16 (+16 B pad)], level 0 as raw fp32
+// [img][3][256] (it is not deduplicated: ds = 1) and, derived from it, a pre-scaled im2col block
+// A0[plane][64 px][64 K bf16 (+16 B pad)] with K = img*32 + tap*3 + c (27 real per image).
+// conv2 phase: H[plane][65 px][512 bf16 (+16 B pad)] overlays all of the above.
+constexpr int ST1 = 144, ST3 = 272;                               // bytes per cell of levels 1/2 and 3
+constexpr int NC1 = 81, NC2 = 25, NC3 = 9;                        // real cells; index NCj is the zero cell
+constexpr int OFF1 = 0;
+constexpr int OFF2 = OFF1 + (NC1 + 1) * ST1;                      // 11808
+constexpr int OFF3 = OFF2 + (NC2 + 1) * ST1;                      // 15552
+constexpr int PLANE = OFF3 + (NC3 + 1) * ST3;                     // 18272
 constexpr int IMGB = 2 * PLANE;                                   // hi plane, lo plane
-constexpr int TILESB = 2 * IMGB;                                  // 89600
+constexpr int TILESB = 2 * IMGB;                                  // 73088
+constexpr int RAW0 = TILESB;                                      // float [2][3][256]
+constexpr int A0OFF = RAW0 + 2 * 3 * 256 * 4;                     // 79232
+constexpr int A0ST = 144;                                         // bytes per pixel row of A0 (64 bf16 + 16)
+constexpr int A0PLANE = 64 * A0ST;                                // 9216
+constexpr int CONV1B = A0OFF + 2 * A0PLANE;                       // 97664
 constexpr int HPIX = 1040;                                        // bytes per pixel row of H (512 bf16 + 16)
 constexpr int HPLANE = 65 * HPIX;                                 // 64 pixels + zero row
-constexpr int UNIONB = 2 * HPLANE;                                // 135200 (>= TILESB)
+constexpr int UNIONB = 2 * HPLANE;                                // 135200
 constexpr int SM_SCALE = UNIONB;                                  // float [2][256]
 constexpr int SM_V = SM_SCALE + 512 * 4;
 constexpr int SM_F1 = SM_V + 512 * 4;
 constexpr int SM_F2 = SM_F1 + 512 * 4;
 constexpr int SM_MISC = SM_F2 + 256 * 4;
 constexpr int SM_BYTES = SM_MISC + 16 * 4;
-static_assert(OFF3 + (NC3 + 1) * ST3 <= PLANE, "plane too small");
-static_assert(TILESB <= UNIONB, "tiles must fit under H");
+static_assert(CONV1B <= UNIONB, "conv1 buffers must fit under H");
+static_assert(PLANE % 16 == 0 && A0OFF % 16 == 0 && HPLANE % 16 == 0, "16-byte alignment of ds_read_b128");
 
 __device__ __forceinline__ unsigned short f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 __device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
@@ -62,20 +70,57 @@ __device__ __forceinline__ float sumsq8(const f32x4 &h, const f32x4 &l, float ss
 
 #define BMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
-// one slab (16 K values): 3 products x 4 output tiles.  bq = {u0 hi, u0 lo, u1 hi, u1 lo}
-#define SLAB_MFMA(C00, C01, C10, C11, AH0, AL0, AH1, AL1, BQ)  \
-    C00 = BMFMA(AH0, BQ[0], C00);                              \
-    C01 = BMFMA(AH0, BQ[2], C01);                              \
-    C10 = BMFMA(AH1, BQ[0], C10);                              \
-    C11 = BMFMA(AH1, BQ[2], C11);                              \
-    C00 = BMFMA(AH0, BQ[1], C00);                              \
-    C01 = BMFMA(AH0, BQ[3], C01);                              \
-    C10 = BMFMA(AH1, BQ[1], C10);                              \
-    C11 = BMFMA(AH1, BQ[3], C11);                              \
-    C00 = BMFMA(AL0, BQ[0], C00);                              \
-    C01 = BMFMA(AL0, BQ[2], C01);                              \
-    C10 = BMFMA(AL1, BQ[0], C10);                              \
-    C11 = BMFMA(AL1, BQ[2], C11);
+// one slab (16 K values): 3 products x 4 output tiles.  BQ = {u0 hi, u0 lo, u1 hi, u1 lo};
+// A = {m-tile0 hi, m-tile0 lo, m-tile1 hi, m-tile1 lo}
+#define SLAB_MFMA(C00, C01, C10, C11, A, BQ)                   \
+    C00 = BMFMA(A[0], BQ[0], C00);                             \
+    C01 = BMFMA(A[0], BQ[2], C01);                             \
+    C10 = BMFMA(A[2], BQ[0], C10);                             \
+    C11 = BMFMA(A[2], BQ[2], C11);                             \
+    C00 = BMFMA(A[0], BQ[1], C00);                             \
+    C01 = BMFMA(A[0], BQ[3], C01);                             \
+    C10 = BMFMA(A[2], BQ[1], C10);                             \
+    C11 = BMFMA(A[2], BQ[3], C11);                             \
+    C00 = BMFMA(A[1], BQ[0], C00);                             \
+    C01 = BMFMA(A[1], BQ[2], C01);                             \
+    C10 = BMFMA(A[3], BQ[0], C10);                             \
+    C11 = BMFMA(A[3], BQ[2], C11);
+
+// weight stream: ring of four register buffers, the load for slab s+3 is issued when slab s starts
+#define LOADB(BUF, SLAB_AHEAD)                                                          \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) BUF[q_] = bp[(SLAB_AHEAD) * 256 + q_ * 64];
+// A fragments of one slab: P0/P1 = this lane's byte address for m-tile 0/1, LO = distance to the lo plane
+#define LOADA(BUF, P0, P1, LO)                                                          \
+    BUF[0] = *(const f32x4 *)(P0); BUF[1] = *(const f32x4 *)((P0) + (LO));             \
+    BUF[2] = *(const f32x4 *)(P1); BUF[3] = *(const f32x4 *)((P1) + (LO));
+// Four consecutive slabs, software-pipelined by hand: while slab s runs on the matrix cores, the
+// weight load for slab s+3 and the LDS reads for slab s+1 are in flight.  A0_/A1_ alternate as the
+// current / next A fragments (the caller pre-loads A0_ with the group's first slab); (NP0, NP1) is the
+// first slab of whatever follows.  sched_barrier keeps the compiler from hoisting later slabs' loads
+// (which blows the register budget).
+#define GROUP4(C00, C01, C10, C11, P0, P1, NP0, NP1, STEP, LO)                                            \
+    { LOADB(B3, 3) LOADA(A1_, (P0) + (STEP), (P1) + (STEP), LO)         SLAB_MFMA(C00, C01, C10, C11, A0_, B0) __builtin_amdgcn_sched_barrier(0); \
+      LOADB(B0, 4) LOADA(A0_, (P0) + 2 * (STEP), (P1) + 2 * (STEP), LO) SLAB_MFMA(C00, C01, C10, C11, A1_, B1) __builtin_amdgcn_sched_barrier(0); \
+      LOADB(B1, 5) LOADA(A1_, (P0) + 3 * (STEP), (P1) + 3 * (STEP), LO) SLAB_MFMA(C00, C01, C10, C11, A0_, B2) __builtin_amdgcn_sched_barrier(0); \
+      LOADB(B2, 6) LOADA(A0_, (NP0), (NP1), LO)                         SLAB_MFMA(C00, C01, C10, C11, A1_, B3) __builtin_amdgcn_sched_barrier(0); \
+      bp += 4 * 256; }
+
+// conv1 variant: one n-tile at a time (two accumulators C0/C1 = m-tile 0/1), units of 2 KiB
+#define SLAB_MFMA6(C0, C1, A, BQ)                              \
+    C0 = BMFMA(A[0], BQ[0], C0);                               \
+    C1 = BMFMA(A[2], BQ[0], C1);                               \
+    C0 = BMFMA(A[0], BQ[1], C0);                               \
+    C1 = BMFMA(A[2], BQ[1], C1);                               \
+    C0 = BMFMA(A[1], BQ[0], C0);                               \
+    C1 = BMFMA(A[3], BQ[0], C1);
+#define LOADB2(BUF, UNIT_AHEAD)                                                         \
+    _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) BUF[q_] = bp[(UNIT_AHEAD) * 128 + q_ * 64];
+#define GROUP4H(C0, C1, P0, P1, NP0, NP1, STEP, LO)                                                       \
+    { LOADB2(B3, 3) LOADA(A1_, (P0) + (STEP), (P1) + (STEP), LO)         SLAB_MFMA6(C0, C1, A0_, B0) __builtin_amdgcn_sched_barrier(0); \
+      LOADB2(B0, 4) LOADA(A0_, (P0) + 2 * (STEP), (P1) + 2 * (STEP), LO) SLAB_MFMA6(C0, C1, A1_, B1) __builtin_amdgcn_sched_barrier(0); \
+      LOADB2(B1, 5) LOADA(A1_, (P0) + 3 * (STEP), (P1) + 3 * (STEP), LO) SLAB_MFMA6(C0, C1, A0_, B2) __builtin_amdgcn_sched_barrier(0); \
+      LOADB2(B2, 6) LOADA(A0_, (NP0), (NP1), LO)                         SLAB_MFMA6(C0, C1, A1_, B3) __builtin_amdgcn_sched_barrier(0); \
+      bp += 4 * 128; }
 
 __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
@@ -88,6 +133,8 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
     int it = 0;
     while (it + 1 < args.nitems && prop >= args.start[it + 1]) ++it;
     const ItemDev &I = args.item[it];
+
+    float *raw0 = (float *)(smb + RAW0);
     float *scale = (float *)(smb + SM_SCALE);
     float *V = (float *)(smb + SM_V);
     float *F1 = (float *)(smb + SM_F1);
@@ -104,37 +151,55 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
 
     for (int lvl = 0; lvl < args.nlevels; ++lvl) {
         const RegDev &R = args.reg[lvl];
-        int x0[2], y0[2];
-        x0[0] = (int)misc[8 + 0] - 8; y0[0] = (int)misc[8 + 1] - 8;
-        x0[1] = (int)misc[8 + 2] - 8; y0[1] = (int)misc[8 + 3] - 8;
+        // window origins (x, y) in image 1 / image 2; scalars + selects, never a runtime-indexed array
+        const int xa = (int)misc[8 + 0] - 8, ya = (int)misc[8 + 1] - 8;
+        const int xb = (int)misc[8 + 2] - 8, yb = (int)misc[8 + 3] - 8;
+#define X0(img_) ((img_) ? xb : xa)
+#define Y0(img_) ((img_) ? yb : ya)
         __syncthreads();
+        // Opaque copy of the thread id for the staging phases: their index arithmetic depends only on the
+        // thread id, and without this the compiler hoists all of it out of the level loop and spills it
+        // (scratch must stay at zero, see build.py).
+        int tidv = tid;
+        asm volatile("" : "+v"(tidv));
 
-        // ------------------------------------------------------------ clear tiles (zero cells, pad channels)
-        for (int e = tid; e < TILESB / 16; e += NT) ((f32x4 *)smb)[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        __syncthreads();
-
-        // ------------------------------------------------------------ gather + split (networks/utils.py:4-36)
+        // ------------------------------------------------------------ zero cells of the tiles
+        if (tidv < 2 * 2 * 3) {
+            const int j = tidv % 3 + 1, plane = (tidv / 3) & 1, img = tidv / 6;
+            const int off = (j == 1) ? OFF1 + NC1 * ST1 : (j == 2) ? OFF2 + NC2 * ST1 : OFF3 + NC3 * ST3;
+            const int nb = (j == 3) ? ST3 : ST1;
+            unsigned char *z = smb + img * IMGB + plane * PLANE + off;
+            for (int q = 0; q < nb; q += 16) *(f32x4 *)(z + q) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        // ------------------------------------------------------------ gather (networks/utils.py:4-36)
         for (int img = 0; img < 2; ++img) {
             const int Hh = I.H[img], Ww = I.W[img];
+            {   // level 0: raw fp32 [3][16x16]
+                const int r0 = clampi(Y0(img), 0, Hh - 1), c0 = clampi(X0(img), 0, Ww - 1);
+                const float *src = I.pyr[img][0];
+                for (int e = tidv; e < 3 * 256; e += NT) {
+                    const int c = e >> 8, rem = e & 255, r = rem >> 4, cc = rem & 15;
+                    raw0[img * 768 + e] = src[((size_t)c * Hh + min(r0 + r, Hh - 1)) * Ww + min(c0 + cc, Ww - 1)];
+                }
+            }
             unsigned char *tb = smb + img * IMGB;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int Rr = (j == 0) ? 16 : (j == 1) ? 9 : (j == 2) ? 5 : 3;
-                const int Cc = (j == 0) ? 3 : (j == 3) ? 128 : 64;
-                const int off = (j == 0) ? OFF0 : (j == 1) ? OFF1 : (j == 2) ? OFF2 : OFF3;
-                const int st = (j == 0) ? ST0 : (j == 3) ? ST3 : ST1;
+            for (int j = 1; j < 4; ++j) {
+                const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
+                const int Cc = (j == 3) ? 128 : 64;
+                const int off = (j == 1) ? OFF1 : (j == 2) ? OFF2 : OFF3;
+                const int st = (j == 3) ? ST3 : ST1;
                 const int Hj = Hh >> j, Wj = Ww >> j;
-                const int r0 = clampi(y0[img] >> j, 0, Hj - 1);
-                const int c0 = clampi(x0[img] >> j, 0, Wj - 1);
+                const int r0 = clampi(Y0(img) >> j, 0, Hj - 1);
+                const int c0 = clampi(X0(img) >> j, 0, Wj - 1);
                 const float *src = I.pyr[img][j];
-                for (int e = tid; e < Cc * Rr * Rr; e += NT) {
+#pragma unroll 4
+                for (int e = tidv; e < Cc * Rr * Rr; e += NT) {
                     const int c = e / (Rr * Rr);
                     const int rem = e - c * (Rr * Rr);
                     const int r = rem / Rr;
                     const int cc = rem - r * Rr;
-                    const int sy = min(r0 + r, Hj - 1);
-                    const int sx = min(c0 + cc, Wj - 1);
-                    const float v = src[((size_t)c * Hj + sy) * Wj + sx];
+                    const float v = src[((size_t)c * Hj + min(r0 + r, Hj - 1)) * Wj + min(c0 + cc, Wj - 1)];
                     const unsigned short hi = f2bf(v);
                     const unsigned short lo = f2bf(v - bf2f(hi));
                     unsigned char *dst = tb + off + rem * st + c * 2;
@@ -147,12 +212,13 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
 
         // ------------------------------------------------------------ per-pixel L2 scale (patch2pix.py:173-174)
         {
-            const int img = tid >> 8, pix = tid & 255, py = pix >> 4, px = pix & 15;
+            const int img = tidv >> 8, pix = tidv & 255, py = pix >> 4, px = pix & 15;
             const unsigned char *tb = smb + img * IMGB;
             float ss = 0.f;
             {
-                const unsigned char *p = tb + OFF0 + (patch_cell(y0[img], py, 0, I.H[img]) * 16 + patch_cell(x0[img], px, 0, I.W[img])) * ST0;
-                ss = sumsq8(*(const f32x4 *)p, *(const f32x4 *)(p + PLANE), ss);
+                const float *p = raw0 + img * 768 + patch_cell(Y0(img), py, 0, I.H[img]) * 16 + patch_cell(X0(img), px, 0, I.W[img]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) ss = fmaf(p[c * 256], p[c * 256], ss);
             }
 #pragma unroll
             for (int j = 1; j < 4; ++j) {
@@ -160,20 +226,49 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
                 const int Cc = (j == 3) ? 128 : 64;
                 const int off = (j == 1) ? OFF1 : (j == 2) ? OFF2 : OFF3;
                 const int st = (j == 3) ? ST3 : ST1;
-                const unsigned char *p = tb + off + (patch_cell(y0[img], py, j, I.H[img]) * Rr + patch_cell(x0[img], px, j, I.W[img])) * st;
+                const unsigned char *p = tb + off + (patch_cell(Y0(img), py, j, I.H[img]) * Rr + patch_cell(X0(img), px, j, I.W[img])) * st;
                 for (int c = 0; c < Cc; c += 8) ss = sumsq8(*(const f32x4 *)(p + c * 2), *(const f32x4 *)(p + c * 2 + PLANE), ss);
             }
             scale[tid] = 1.0f / sqrtf(ss + 1e-6f);
         }
         __syncthreads();
 
+        // ------------------------------------------------------------ level-0 im2col block, pre-scaled and split
+        for (int e = tidv; e < 64 * 64; e += NT) {
+            const int m = e >> 6, kk = e & 63, img = kk >> 5, r = kk & 31;
+            float v = 0.f;
+            if (r < 27) {
+                const int tap = r / 3, c = r - tap * 3, ky = tap / 3, kx = tap - ky * 3;
+                const int py = 2 * (m >> 3) + ky - 1, px = 2 * (m & 7) + kx - 1;
+                if (py >= 0 && px >= 0)
+                    v = raw0[img * 768 + c * 256 + patch_cell(Y0(img), py, 0, I.H[img]) * 16 + patch_cell(X0(img), px, 0, I.W[img])] *
+                        scale[img * 256 + py * 16 + px];
+            }
+            const unsigned short hi = f2bf(v);
+            const unsigned short lo = f2bf(v - bf2f(hi));
+            unsigned char *dst = smb + A0OFF + m * A0ST + kk * 2;
+            *(unsigned short *)dst = hi;
+            *(unsigned short *)(dst + A0PLANE) = lo;
+        }
+        __syncthreads();
+
         // ------------------------------------------------------------ conv1: 3x3, stride 2, pad 1
         f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
         {
-            const f32x4 *bp = (const f32x4 *)R.ws1 + (size_t)wave * (S1_SLABS + SPF) * 256 + lane;
-            f32x4 bc[4], bn[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { bc[q] = bp[q * 64]; bn[q] = bp[256 + q * 64]; }
+            const f32x4 *bp = (const f32x4 *)R.ws1 + (size_t)wave * (S1_UNITS + SPF) * 128 + lane;
+            f32x4 B0[2], B1[2], B2[2], B3[2], A0_[4], A1_[4];
+#ifdef P2P_SPLIT_SKIP_CONV
+            if (args.n < 0)     // never true: timing experiment without the MFMA loops
+#endif
+            {
+            LOADB2(B0, 0) LOADB2(B1, 1) LOADB2(B2, 2)
+            {   // level 0 of both images: 4 slabs per n-tile, already scaled -> straight into the accumulators
+                const unsigned char *p0 = smb + A0OFF + l31 * A0ST + half * 16;
+                const unsigned char *p1 = p0 + 32 * A0ST;
+                LOADA(A0_, p0, p1, A0PLANE)
+                GROUP4H(acc00, acc10, p0, p1, p0, p1, 32, A0PLANE)
+                GROUP4H(acc01, acc11, p0, p1, p0, p1, 32, A0PLANE)
+            }
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap - ky * 3;
@@ -189,63 +284,42 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
                 }
 #pragma unroll 1
                 for (int img = 0; img < 2; ++img) {
-                    // byte addresses of this lane's A fragments, per m-tile and level
-                    int ab[2][4];
+                    // byte addresses of this lane's A fragments, per m-tile and level (zero cell when padding)
+                    int ab[2][3];            // LDS byte offsets
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int tb = img * IMGB;
-                        const int c0 = patch_cell(y0[img], pyc[t], 0, I.H[img]) * 16 + patch_cell(x0[img], pxc[t], 0, I.W[img]);
-                        ab[t][0] = tb + OFF0 + ((ok[t] && half == 0) ? c0 : NC0) * ST0;
+                    for (int t = 0; t < 2; ++t)
 #pragma unroll
                         for (int j = 1; j < 4; ++j) {
                             const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
                             const int off = (j == 1) ? OFF1 : (j == 2) ? OFF2 : OFF3;
                             const int st = (j == 3) ? ST3 : ST1;
-                            const int cj = patch_cell(y0[img], pyc[t], j, I.H[img]) * Rr + patch_cell(x0[img], pxc[t], j, I.W[img]);
-                            ab[t][j] = tb + off + (ok[t] ? cj : Rr * Rr) * st + half * 16;
+                            const int cj = patch_cell(Y0(img), pyc[t], j, I.H[img]) * Rr + patch_cell(X0(img), pxc[t], j, I.W[img]);
+                            ab[t][j - 1] = img * IMGB + off + (ok[t] ? cj : Rr * Rr) * st + half * 16;
                         }
-                    }
-                    f32x16 t00 = {0}, t01 = {0}, t10 = {0}, t11 = {0};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int nslab = (j == 0) ? 1 : (j == 3) ? 8 : 4;
-                        const unsigned char *q0 = smb + ab[0][j], *q1 = smb + ab[1][j];
-#pragma unroll 2
-                        for (int kin = 0; kin < nslab; ++kin) {
-                            const f32x4 ah0 = *(const f32x4 *)(q0 + kin * 32);
-                            const f32x4 al0 = *(const f32x4 *)(q0 + kin * 32 + PLANE);
-                            const f32x4 ah1 = *(const f32x4 *)(q1 + kin * 32);
-                            const f32x4 al1 = *(const f32x4 *)(q1 + kin * 32 + PLANE);
-                            f32x4 nn[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) nn[q] = bp[256 * SPF + q * 64];
-                            bp += 256;
-                            SLAB_MFMA(t00, t01, t10, t11, ah0, al0, ah1, al1, bc)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) { bc[q] = bn[q]; bn[q] = nn[q]; }
-                        }
-                    }
-                    // fold the unscaled (tap, image) partial sums in with the per-pixel scale of their source pixel
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
+                    for (int u = 0; u < 2; ++u) {
+                        f32x16 t0 = {0}, t1 = {0};
+                        LOADA(A0_, smb + ab[0][0], smb + ab[1][0], PLANE)
+                        GROUP4H(t0, t1, smb + ab[0][0], smb + ab[1][0], smb + ab[0][1], smb + ab[1][1], 32, PLANE)               // level 1
+                        GROUP4H(t0, t1, smb + ab[0][1], smb + ab[1][1], smb + ab[0][2], smb + ab[1][2], 32, PLANE)               // level 2
+                        GROUP4H(t0, t1, smb + ab[0][2], smb + ab[1][2], smb + ab[0][2] + 128, smb + ab[1][2] + 128, 32, PLANE)   // level 3
+                        GROUP4H(t0, t1, smb + ab[0][2] + 128, smb + ab[1][2] + 128, smb + ab[0][0], smb + ab[1][0], 32, PLANE)
+                        // fold the unscaled partial sums in with the scale of the source pixel of each row
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int py = 2 * (4 * t + (r >> 2)) + ky - 1, px = 2 * (4 * half + (r & 3)) + kx - 1;
-                            const float sv = scale[img * 256 + max(py, 0) * 16 + max(px, 0)];
-                            if (t == 0) { acc00[r] = fmaf(sv, t00[r], acc00[r]); acc01[r] = fmaf(sv, t01[r], acc01[r]); }
-                            else        { acc10[r] = fmaf(sv, t10[r], acc10[r]); acc11[r] = fmaf(sv, t11[r], acc11[r]); }
+                            const int px = 2 * (4 * half + (r & 3)) + kx - 1;
+                            const int py0 = 2 * (r >> 2) + ky - 1, py1 = py0 + 8;
+                            const float s0 = scale[img * 256 + max(py0, 0) * 16 + max(px, 0)];
+                            const float s1 = scale[img * 256 + py1 * 16 + max(px, 0)];
+                            if (u == 0) { acc00[r] = fmaf(s0, t0[r], acc00[r]); acc10[r] = fmaf(s1, t1[r], acc10[r]); }
+                            else        { acc01[r] = fmaf(s0, t0[r], acc01[r]); acc11[r] = fmaf(s1, t1[r], acc11[r]); }
                         }
+                    }
                 }
             }
+            }
         }
-        __syncthreads();   // all waves are done reading the patch tiles
-#ifdef P2P_DEBUG_SPLIT
-        if (prop == 0 && lvl == 0 && tid == 0) {
-            printf("DBG scale %g %g %g %g | %g %g\n", scale[0], scale[1], scale[17], scale[255], scale[256], scale[256 + 100]);
-            printf("DBG acc00 (n=0; px 0,1,2,3) %g %g %g %g  acc01 (n=32) %g  acc10 (px32) %g\n", acc00[0], acc00[1], acc00[2], acc00[3], acc01[0], acc10[0]);
-        }
-        if (prop == 0 && lvl == 0 && tid == 33) printf("DBG lane33 acc00[0] (n=1, px 4) %g\n", acc00[0]);
-#endif
+        __syncthreads();   // all waves are done reading the conv1 operands
 
         // BN1 -> split -> H[pixel][channel] (bf16 hi / lo planes), plus the all-zero padding row
         {
@@ -279,9 +353,11 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
         acc00 = (f32x16){0}; acc01 = (f32x16){0}; acc10 = (f32x16){0}; acc11 = (f32x16){0};
         {
             const f32x4 *bp = (const f32x4 *)R.ws2 + (size_t)wave * (S2_SLABS + SPF) * 256 + lane;
-            f32x4 bc[4], bn[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { bc[q] = bp[q * 64]; bn[q] = bp[256 + q * 64]; }
+            f32x4 B0[4], B1[4], B2[4], B3[4], A0_[4], A1_[4];
+            LOADB(B0, 0) LOADB(B1, 1) LOADB(B2, 2)
+#ifdef P2P_SPLIT_SKIP_CONV
+            if (args.n < 0)
+#endif
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap - ky * 3;
@@ -291,19 +367,11 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
                 const bool ok1 = okx && (oy + 4 < 8);
                 const unsigned char *p0 = smb + (ok0 ? oy * 8 + ox : 64) * HPIX + half * 16;
                 const unsigned char *p1 = smb + (ok1 ? (oy + 4) * 8 + ox : 64) * HPIX + half * 16;
-#pragma unroll 4
-                for (int s = 0; s < 32; ++s) {
-                    const f32x4 ah0 = *(const f32x4 *)(p0 + s * 32);
-                    const f32x4 al0 = *(const f32x4 *)(p0 + s * 32 + HPLANE);
-                    const f32x4 ah1 = *(const f32x4 *)(p1 + s * 32);
-                    const f32x4 al1 = *(const f32x4 *)(p1 + s * 32 + HPLANE);
-                    f32x4 nn[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) nn[q] = bp[256 * SPF + q * 64];
-                    bp += 256;
-                    SLAB_MFMA(acc00, acc01, acc10, acc11, ah0, al0, ah1, al1, bc)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { bc[q] = bn[q]; bn[q] = nn[q]; }
+                LOADA(A0_, p0, p1, HPLANE)
+#pragma unroll 1
+                for (int g = 0; g < 8; ++g) {
+                    const int gn = (g < 7) ? g + 1 : 7;      // the last group's look-ahead re-reads its own data
+                    GROUP4(acc00, acc01, acc10, acc11, p0 + g * 128, p1 + g * 128, p0 + gn * 128, p1 + gn * 128, 32, HPLANE)
                 }
             }
         }
@@ -348,30 +416,44 @@ static float bf16_to_f(uint16_t b) {
     return f;
 }
 
-// channel (0..517) of the concatenated regressor input for position (sin, half, j) of a conv1 slab of image `img`
-static int split_conv1_channel(int img, int sin, int half, int j) {
-    if (sin == 0) return (half == 0 && j < 3) ? img * 259 + j : -1;
-    const int base = (sin < 5) ? 3 + (sin - 1) * 16 : (sin < 9) ? 67 + (sin - 5) * 16 : 131 + (sin - 9) * 16;
-    return img * 259 + base + 8 * half + j;
+// conv1 K layout (see the kernel): slabs 0-3 hold level 0 of both images with K = img*32 + tap*3 + c;
+// slab 4 + (tap*2 + img)*16 + s holds 16 channels of level 1 (s 0-3), 2 (s 4-7) or 3 (s 8-15) of image `img`.
+// Returns the channel (0..517) of the concatenated regressor input and the tap, or ch = -1 for padding.
+static void split_conv1_index(int slab, int half, int j, int &ch, int &tap) {
+    if (slab < 4) {
+        const int kk = slab * 16 + 8 * half + j, img = kk >> 5, r = kk & 31;
+        if (r >= 27) { ch = -1; tap = 0; return; }
+        tap = r / 3;
+        ch = img * 259 + (r % 3);
+        return;
+    }
+    const int q = slab - 4, s = q % 16, img = (q / 16) % 2;
+    tap = q / 32;
+    const int base = (s < 4) ? 3 + s * 16 : (s < 8) ? 67 + (s - 4) * 16 : 131 + (s - 8) * 16;
+    ch = img * 259 + base + 8 * half + j;
 }
 
 void pack_split_weights(const float *conv1_w, const float *conv2_w, float *ws1, float *ws2) {
     uint16_t *d1 = (uint16_t *)ws1, *d2 = (uint16_t *)ws2;
+    // conv1 stream order per wave: level 0 [u][4 slabs], then [tap][img][u][16 slabs]; 2 KiB units [plane][lane][8]
     for (int w = 0; w < 8; ++w)
-        for (int slab = 0; slab < S1_SLABS; ++slab) {
-            const int tap = slab / 34, img = (slab % 34) / 17, sin = slab % 17;
-            for (int u = 0; u < 2; ++u)
+        for (int slab = 0; slab < S1_SLABS; ++slab)
+            for (int u = 0; u < 2; ++u) {
+                int unit;
+                if (slab < 4) unit = u * 4 + slab;
+                else { const int q = slab - 4; unit = 8 + ((q / 16) * 2 + u) * 16 + (q % 16); }
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
                         const int n = 64 * w + 32 * u + (lane & 31);
-                        const int ch = split_conv1_channel(img, sin, lane >> 5, j);
+                        int ch, tap;
+                        split_conv1_index(slab, lane >> 5, j, ch, tap);
                         const float v = (ch < 0) ? 0.f : conv1_w[((size_t)n * 518 + ch) * 9 + tap];
                         const uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f(hi));
-                        const size_t base = ((((size_t)w * (S1_SLABS + SPF) + slab) * 2 + u) * 2) * 64;
+                        const size_t base = (((size_t)w * (S1_UNITS + SPF) + unit) * 2) * 64;
                         d1[((base + lane) * 8) + j] = hi;
                         d1[((base + 64 + lane) * 8) + j] = lo;
                     }
-        }
+            }
     for (int w = 0; w < 8; ++w)
         for (int slab = 0; slab < S2_SLABS; ++slab) {
             const int tap = slab / 32, sin = slab % 32;

@@ -33,13 +33,18 @@ def ops():
     return ops
 
 
-@pytest.fixture(scope="module")
-def weights(dev, ops):
+@pytest.fixture(scope="module", params=["bf16x2", "f32"])
+def weights(dev, ops, request):
+    """Both arithmetic modes of the regressor kernels are held to the same bars."""
     sd = gu.state_dict(0)
     ncn = ops.NcnWeights(sd["ncn.conv.0.weight"], sd["ncn.conv.0.bias"], sd["ncn.conv.2.weight"],
                          sd["ncn.conv.2.bias"], dev)
     sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
-    return sd, ncn, ops.RegressorWeights(sub("regress_mid."), dev), ops.RegressorWeights(sub("regress_fine."), dev)
+    mid, fine = ops.RegressorWeights(sub("regress_mid."), dev), ops.RegressorWeights(sub("regress_fine."), dev)
+    mid.set_mode(request.param)
+    fine.set_mode(request.param)
+    assert mid.mode == request.param
+    return sd, ncn, mid, fine
 
 
 def _gpu(pyr, dev):
