@@ -129,6 +129,8 @@ class Patch2Pix(nn.Module):
         self.to(self.device)
         self._packed = None
         self._copy_stream = None
+        self._pinned = {}        # up to 4 tickets in flight per shape
+        self._pin_turn = 0
         self.init_weights_(weights_dict=config.weights_dict)
         self.eval()
 
@@ -269,8 +271,13 @@ class Patch2Pix(nn.Module):
         main = torch.cuda.current_stream(self.device)
         ready = torch.cuda.Event()
         ready.record(main)
-        host_m = torch.empty(matches_.shape, dtype=matches_.dtype, pin_memory=True)
-        host_s = torch.empty(score_.shape, dtype=score_.dtype, pin_memory=True)
+        # pinned staging buffers are recycled (allocating pinned memory synchronises with the device)
+        key = (tuple(matches_.shape), self._pin_turn)
+        self._pin_turn = (self._pin_turn + 1) % 4
+        if key not in self._pinned:
+            self._pinned[key] = (torch.empty(matches_.shape, dtype=matches_.dtype, pin_memory=True),
+                                 torch.empty(score_.shape, dtype=score_.dtype, pin_memory=True))
+        host_m, host_s = self._pinned[key]
         with torch.cuda.stream(self._copy_stream):
             self._copy_stream.wait_event(ready)
             host_m.copy_(matches_, non_blocking=True)
