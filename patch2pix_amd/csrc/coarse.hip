@@ -32,33 +32,48 @@ constexpr int KEY_NEG_INF = (int)0xff800000 ^ 0x7fffffff;
 // ------------------------------------------------------------------------------------------------
 // 1. L2 normalise + transpose to position-major with cell-major position order (modules.py:6)
 // ------------------------------------------------------------------------------------------------
+constexpr int PREP_P = 16;    // positions per work-group (300 groups at 60x80: fills the chip)
 __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ F, float *__restrict__ Fn, int C, int h,
                                                    int w, int k) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];   // [C][65]
-    __shared__ float inv[64];
+    __shared__ float tile[256 * (PREP_P + 1)];   // [C <= 256][17]
+    __shared__ float part[16][PREP_P];
+    __shared__ float inv[PREP_P];
     const int hw = h * w;
-    const int p0 = blockIdx.x * 64;
+    const int p0 = blockIdx.x * PREP_P;
     const int tid = threadIdx.x;
-    for (int e = tid; e < C * 64; e += 256) {
-        const int c = e >> 6, p = e & 63;
-        tile[c * 65 + p] = (p0 + p < hw) ? F[(size_t)c * hw + p0 + p] : 0.f;
+    // 4 threads x float4 cover the 16 positions of one channel row (64 contiguous bytes)
+    for (int e = tid; e < C * 4; e += 256) {
+        const int c = e >> 2, q = e & 3;
+        const int pos = p0 + 4 * q;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (pos + 3 < hw && (hw & 3) == 0) v = *(const f32x4 *)(F + (size_t)c * hw + pos);
+        else
+            for (int i = 0; i < 4; ++i) if (pos + i < hw) v[i] = F[(size_t)c * hw + pos + i];
+        float *t = tile + c * (PREP_P + 1) + 4 * q;
+        t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
     }
     __syncthreads();
-    if (tid < 64) {
+    {   // sum of squares: 16 channel groups x 16 positions, ascending channel order within a group
+        const int p = tid & 15, g = tid >> 4;
         float ss = 0.f;
-        for (int c = 0; c < C; ++c) { float v = tile[c * 65 + tid]; ss = fmaf(v, v, ss); }
+        for (int c = g; c < C; c += 16) { const float v = tile[c * (PREP_P + 1) + p]; ss = fmaf(v, v, ss); }
+        part[g][p] = ss;
+    }
+    __syncthreads();
+    if (tid < PREP_P) {
+        float ss = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) ss += part[g][tid];
         inv[tid] = 1.0f / sqrtf(ss + 1e-6f);
     }
     __syncthreads();
     const int wc = w / k;
-    for (int e = tid; e < C * 64; e += 256) {
-        const int p = e / C, c = e - p * C;
+    for (int p = 0; p < PREP_P; ++p) {
         const int pos = p0 + p;
-        if (pos < hw) {
-            const int i = pos / w, j = pos - i * w;
-            const int pp = ((i / k) * wc + (j / k)) * (k * k) + (i % k) * k + (j % k);
-            Fn[(size_t)pp * C + c] = tile[c * 65 + p] * inv[p];
-        }
+        if (pos >= hw) break;
+        const int i = pos / w, j = pos - i * w;
+        const int pp = ((i / k) * wc + (j / k)) * (k * k) + (i % k) * k + (j % k);
+        for (int c = tid; c < C; c += 256) Fn[(size_t)pp * C + c] = tile[c * (PREP_P + 1) + p] * inv[p];
     }
 }
 
@@ -169,21 +184,27 @@ __global__ void fill_keys_kernel(int *p, int n) {
     if (i < n) p[i] = KEY_NEG_INF;
 }
 
-__global__ __launch_bounds__(256) void rowcolmax_kernel(const float *__restrict__ X, int nA, int nB, int *rkey,
-                                                        int *ckey) {
+// column maxima: a thread owns one column over a 64-row chunk; chunks meet in an (order independent) atomicMax
+__global__ __launch_bounds__(256) void colmax_kernel(const float *__restrict__ X, int nA, int nB, int *ckey) {
     const int col = blockIdx.x * 256 + threadIdx.x;
-    const int r0 = blockIdx.y * 64;
-    const bool colok = col < nB;
+    if (col >= nB) return;
+    const int r0 = blockIdx.y * 64, r1 = min(r0 + 64, nA);
     float cm = -INFINITY;
-    for (int r = r0; r < min(r0 + 64, nA); ++r) {
-        const float v = colok ? X[(size_t)r * nB + col] : -INFINITY;
-        cm = fmaxf(cm, v);
-        float rm = v;
+#pragma unroll 8
+    for (int r = r0; r < r1; ++r) cm = fmaxf(cm, X[(size_t)r * nB + col]);
+    atomicMax(&ckey[col], f2key(cm));
+}
+
+// row maxima: one wave per row
+__global__ __launch_bounds__(256) void rowmax_kernel(const float *__restrict__ X, int nA, int nB, int *rkey) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= nA) return;
+    const float *x = X + (size_t)row * nB;
+    float rm = -INFINITY;
+    for (int c = lane; c < nB; c += 64) rm = fmaxf(rm, x[c]);
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) rm = fmaxf(rm, __shfl_xor(rm, m));
-        if ((threadIdx.x & 63) == 0) atomicMax(&rkey[r], f2key(rm));
-    }
-    if (colok) atomicMax(&ckey[col], f2key(cm));
+    for (int m = 32; m >= 1; m >>= 1) rm = fmaxf(rm, __shfl_xor(rm, m));
+    if (lane == 0) rkey[row] = f2key(rm);
 }
 
 // MutualMatching value (ncn/model.py:168-175): x * ((x / (max_over_B + eps)) * (x / (max_over_A + eps)))
@@ -425,19 +446,19 @@ __device__ __forceinline__ void emit_match(const MatchArgs &m, int out_row, int 
     m.scores[out_row] = 1.0f / sum_exp;       // max of softmax = exp(0) / sum exp(x - max)
 }
 
-// direction B->A: one block per 32 columns, 8 interleaved row slices
+// direction B->A: one block per 8 columns, 32 interleaved row slices
 __global__ __launch_bounds__(256) void match_cols_kernel(MatchArgs m) {
-    __shared__ float smax[8][32];
-    __shared__ int sarg[8][32];
-    __shared__ float ssum[8][32];
+    __shared__ float smax[32][8];
+    __shared__ int sarg[32][8];
+    __shared__ float ssum[32][8];
     const int nA = m.hA * m.wA, nB = m.hB * m.wB;
-    const int cs = threadIdx.x & 31, rs = threadIdx.x >> 5;
-    const int col = blockIdx.x * 32 + cs;
+    const int cs = threadIdx.x & 7, rs = threadIdx.x >> 3;
+    const int col = blockIdx.x * 8 + cs;
     const bool ok = col < nB;
     float best = -INFINITY;
     int arg = 0x7fffffff;
     if (ok)
-        for (int r = rs; r < nA; r += 8) {
+        for (int r = rs; r < nA; r += 32) {
             const float v = m.X[(size_t)r * nB + col];
             if (v > best) { best = v; arg = r; }
         }
@@ -446,20 +467,20 @@ __global__ __launch_bounds__(256) void match_cols_kernel(MatchArgs m) {
     float gb = smax[0][cs];
     int ga = sarg[0][cs];
 #pragma unroll
-    for (int s = 1; s < 8; ++s) {
+    for (int s = 1; s < 32; ++s) {
         const float v = smax[s][cs];
         const int a = sarg[s][cs];
         if (v > gb || (v == gb && a < ga)) { gb = v; ga = a; }
     }
     float sum = 0.f;
     if (ok)
-        for (int r = rs; r < nA; r += 8) sum += expf(m.X[(size_t)r * nB + col] - gb);
+        for (int r = rs; r < nA; r += 32) sum += expf(m.X[(size_t)r * nB + col] - gb);
     ssum[rs][cs] = sum;
     __syncthreads();
     if (rs == 0 && ok) {
         float t = 0.f;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) t += ssum[s][cs];
+        for (int s = 0; s < 32; ++s) t += ssum[s][cs];
         emit_match(m, col, ga, col, t);
     }
 }
@@ -587,14 +608,8 @@ extern "C" int p2p_coarse_forward(const float *featA, const float *featB, int C,
     const int nAc = nA / kk, nBc = nB / kk;
     int *rkey1 = (int *)(base + ws.keys), *ckey1 = rkey1 + nAc, *rkey2 = ckey1 + nBc, *ckey2 = rkey2 + nAc;
 
-    const size_t prep_lds = (size_t)C * 65 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        P2P_HIP_CHECK(hipFuncSetAttribute((const void *)prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 65 * 4));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(prep_kernel, dim3(ceil_div(nA, 64)), dim3(256), prep_lds, stream, featA, fnA, C, hA, wA, ksize);
-    hipLaunchKernelGGL(prep_kernel, dim3(ceil_div(nB, 64)), dim3(256), prep_lds, stream, featB, fnB, C, hB, wB, ksize);
+    hipLaunchKernelGGL(prep_kernel, dim3(ceil_div(nA, PREP_P)), dim3(256), 0, stream, featA, fnA, C, hA, wA, ksize);
+    hipLaunchKernelGGL(prep_kernel, dim3(ceil_div(nB, PREP_P)), dim3(256), 0, stream, featB, fnB, C, hB, wB, ksize);
     const dim3 cgrid(ceil_div(nB, CT), ceil_div(nA, CT));
     if (ksize == 1)
         hipLaunchKernelGGL(corr_pool_kernel<1>, cgrid, dim3(256), 0, stream, fnA, fnB, nA, nB, C, P, (uint8_t *)nullptr);
@@ -604,7 +619,8 @@ extern "C" int p2p_coarse_forward(const float *featA, const float *featB, int C,
     const int nkeys = 2 * (nAc + nBc);
     hipLaunchKernelGGL(fill_keys_kernel, dim3(ceil_div(nkeys, 256)), dim3(256), 0, stream, rkey1, nkeys);
     const dim3 mgrid(ceil_div(nBc, 256), ceil_div(nAc, 64));
-    hipLaunchKernelGGL(rowcolmax_kernel, mgrid, dim3(256), 0, stream, P, nAc, nBc, rkey1, ckey1);
+    hipLaunchKernelGGL(colmax_kernel, mgrid, dim3(256), 0, stream, P, nAc, nBc, ckey1);
+    hipLaunchKernelGGL(rowmax_kernel, dim3(ceil_div(nAc, 4)), dim3(256), 0, stream, P, nAc, nBc, rkey1);
 
     Vol v{hA / ksize, wA / ksize, hB / ksize, wB / ksize};
     const int ntiles = v.d0 * ceil_div(v.d1, TB_) * ceil_div(v.d2, TC_) * ceil_div(v.d3, TD_);
@@ -613,7 +629,8 @@ extern "C" int p2p_coarse_forward(const float *featA, const float *featB, int C,
     const int ntiles2 = v.d0 * ceil_div(v.d1, nt.tb) * ceil_div(v.d2, nt.tc) * ceil_div(v.d3, 8 * nt.tdr);
     const size_t lds2 = (size_t)3 * (nt.tb + 2) * (nt.tc + 2) * (nt.rs + 1) * 4;
     hipLaunchKernelGGL(nc_layer2_kernel, dim3(ntiles2), dim3(256), lds2, stream, H1, v, nt, ncn->w2cat, ncn->b2, Y);
-    hipLaunchKernelGGL(rowcolmax_kernel, mgrid, dim3(256), 0, stream, Y, nAc, nBc, rkey2, ckey2);
+    hipLaunchKernelGGL(colmax_kernel, mgrid, dim3(256), 0, stream, Y, nAc, nBc, ckey2);
+    hipLaunchKernelGGL(rowmax_kernel, dim3(ceil_div(nAc, 4)), dim3(256), 0, stream, Y, nAc, nBc, rkey2);
     const size_t nel = (size_t)nAc * nBc;
     hipLaunchKernelGGL(mm_apply_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, stream, Y, nAc, nBc, rkey2, ckey2,
                        corr4d_out);
@@ -635,7 +652,7 @@ extern "C" int p2p_coarse_matches(const float *corr4d, const uint8_t *delta, int
     P2P_REQUIRE(ksize == 1 || delta, P2P_EINVAL, "p2p_coarse_matches: delta required when ksize > 1");
     MatchArgs m{corr4d, delta, hA, wA, hB, wB, ksize, upsample, center, (long long *)matches_out, scores_out};
     const int nA = hA * wA, nB = hB * wB;
-    hipLaunchKernelGGL(match_cols_kernel, dim3(ceil_div(nB, 32)), dim3(256), 0, (hipStream_t)stream, m);
+    hipLaunchKernelGGL(match_cols_kernel, dim3(ceil_div(nB, 8)), dim3(256), 0, (hipStream_t)stream, m);
     hipLaunchKernelGGL(match_rows_kernel, dim3(ceil_div(nA, 4)), dim3(256), 0, (hipStream_t)stream, m);
     return check_launch("match kernels");
 }
