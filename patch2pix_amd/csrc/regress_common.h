@@ -100,11 +100,11 @@ __device__ __forceinline__ void fc_tail_parse(const RegDev &R, const ItemDev &I,
 constexpr int S1_SLABS = 4 + 9 * 2 * 16; // conv1: 4 slabs of level 0 (3 ch x 9 taps x 2 images, padded 54 -> 64), then per
                                         // (tap, image) 4 + 4 + 8 slabs of 16 channels of levels 1, 2, 3
 constexpr int S2_SLABS = 9 * 32;        // conv2: 512 channels / 16 per tap
-constexpr int SPF = 3;                  // weight prefetch distance in slabs = ring of 4 register buffers
+constexpr int SPF = 7;                  // weight prefetch distance in units = ring of 8 register buffers
 constexpr int S1_UNITS = 2 * S1_SLABS;   // conv1 streams one n-tile at a time: unit = (slab, n-tile), 2 KiB per (wave, unit)
 constexpr size_t WS1_FLOATS = (size_t)8 * (S1_UNITS + SPF) * 512;
-// conv2: 4 KiB per (wave, slab)
-constexpr size_t WS2_FLOATS = (size_t)8 * (S2_SLABS + SPF) * 1024;
+constexpr int S2_UNITS = 2 * S2_SLABS;   // conv2 likewise: [tap][n-tile][32 slabs]
+constexpr size_t WS2_FLOATS = (size_t)8 * (S2_UNITS + SPF) * 512;
 void pack_split_weights(const float *conv1_w, const float *conv2_w, float *ws1, float *ws2);   // host
 int launch_regress_split(const RegressArgs &a, int n, hipStream_t stream);
 

@@ -70,42 +70,13 @@ __device__ __forceinline__ float sumsq8(const f32x4 &h, const f32x4 &l, float ss
 
 #define BMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
-// one slab (16 K values): 3 products x 4 output tiles.  BQ = {u0 hi, u0 lo, u1 hi, u1 lo};
-// A = {m-tile0 hi, m-tile0 lo, m-tile1 hi, m-tile1 lo}
-#define SLAB_MFMA(C00, C01, C10, C11, A, BQ)                   \
-    C00 = BMFMA(A[0], BQ[0], C00);                             \
-    C01 = BMFMA(A[0], BQ[2], C01);                             \
-    C10 = BMFMA(A[2], BQ[0], C10);                             \
-    C11 = BMFMA(A[2], BQ[2], C11);                             \
-    C00 = BMFMA(A[0], BQ[1], C00);                             \
-    C01 = BMFMA(A[0], BQ[3], C01);                             \
-    C10 = BMFMA(A[2], BQ[1], C10);                             \
-    C11 = BMFMA(A[2], BQ[3], C11);                             \
-    C00 = BMFMA(A[1], BQ[0], C00);                             \
-    C01 = BMFMA(A[1], BQ[2], C01);                             \
-    C10 = BMFMA(A[3], BQ[0], C10);                             \
-    C11 = BMFMA(A[3], BQ[2], C11);
-
-// weight stream: ring of four register buffers, the load for slab s+3 is issued when slab s starts
-#define LOADB(BUF, SLAB_AHEAD)                                                          \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) BUF[q_] = bp[(SLAB_AHEAD) * 256 + q_ * 64];
 // A fragments of one slab: P0/P1 = this lane's byte address for m-tile 0/1, LO = distance to the lo plane
 #define LOADA(BUF, P0, P1, LO)                                                          \
     BUF[0] = *(const f32x4 *)(P0); BUF[1] = *(const f32x4 *)((P0) + (LO));             \
     BUF[2] = *(const f32x4 *)(P1); BUF[3] = *(const f32x4 *)((P1) + (LO));
-// Four consecutive slabs, software-pipelined by hand: while slab s runs on the matrix cores, the
-// weight load for slab s+3 and the LDS reads for slab s+1 are in flight.  A0_/A1_ alternate as the
-// current / next A fragments (the caller pre-loads A0_ with the group's first slab); (NP0, NP1) is the
-// first slab of whatever follows.  sched_barrier keeps the compiler from hoisting later slabs' loads
-// (which blows the register budget).
-#define GROUP4(C00, C01, C10, C11, P0, P1, NP0, NP1, STEP, LO)                                            \
-    { LOADB(B3, 3) LOADA(A1_, (P0) + (STEP), (P1) + (STEP), LO)         SLAB_MFMA(C00, C01, C10, C11, A0_, B0) __builtin_amdgcn_sched_barrier(0); \
-      LOADB(B0, 4) LOADA(A0_, (P0) + 2 * (STEP), (P1) + 2 * (STEP), LO) SLAB_MFMA(C00, C01, C10, C11, A1_, B1) __builtin_amdgcn_sched_barrier(0); \
-      LOADB(B1, 5) LOADA(A1_, (P0) + 3 * (STEP), (P1) + 3 * (STEP), LO) SLAB_MFMA(C00, C01, C10, C11, A0_, B2) __builtin_amdgcn_sched_barrier(0); \
-      LOADB(B2, 6) LOADA(A0_, (NP0), (NP1), LO)                         SLAB_MFMA(C00, C01, C10, C11, A1_, B3) __builtin_amdgcn_sched_barrier(0); \
-      bp += 4 * 256; }
 
-// conv1 variant: one n-tile at a time (two accumulators C0/C1 = m-tile 0/1), units of 2 KiB
+// One unit = one slab (16 K values) x one n-tile: 3 products x 2 m-tiles = 6 MFMAs, 2 KiB of weights
+// per wave.  A = {m-tile0 hi, m-tile0 lo, m-tile1 hi, m-tile1 lo}, BQ = {hi, lo}.
 #define SLAB_MFMA6(C0, C1, A, BQ)                              \
     C0 = BMFMA(A[0], BQ[0], C0);                               \
     C1 = BMFMA(A[2], BQ[0], C1);                               \
@@ -115,12 +86,31 @@ __device__ __forceinline__ float sumsq8(const f32x4 &h, const f32x4 &l, float ss
     C1 = BMFMA(A[3], BQ[0], C1);
 #define LOADB2(BUF, UNIT_AHEAD)                                                         \
     _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) BUF[q_] = bp[(UNIT_AHEAD) * 128 + q_ * 64];
-#define GROUP4H(C0, C1, P0, P1, NP0, NP1, STEP, LO)                                                       \
-    { LOADB2(B3, 3) LOADA(A1_, (P0) + (STEP), (P1) + (STEP), LO)         SLAB_MFMA6(C0, C1, A0_, B0) __builtin_amdgcn_sched_barrier(0); \
-      LOADB2(B0, 4) LOADA(A0_, (P0) + 2 * (STEP), (P1) + 2 * (STEP), LO) SLAB_MFMA6(C0, C1, A1_, B1) __builtin_amdgcn_sched_barrier(0); \
-      LOADB2(B1, 5) LOADA(A1_, (P0) + 3 * (STEP), (P1) + 3 * (STEP), LO) SLAB_MFMA6(C0, C1, A0_, B2) __builtin_amdgcn_sched_barrier(0); \
-      LOADB2(B2, 6) LOADA(A0_, (NP0), (NP1), LO)                         SLAB_MFMA6(C0, C1, A1_, B3) __builtin_amdgcn_sched_barrier(0); \
+// Eight consecutive units, software-pipelined by hand: while unit s runs on the matrix cores, the weight
+// load for unit s+7 (ring of eight register buffers B0..B7) and the LDS reads for unit s+1 (A0_/A1_
+// alternate) are in flight.  The caller pre-loads A0_ with the group's first unit.  (PA0,PA1) / (PB0,PB1)
+// are the lane's A addresses of units 0-3 / 4-7 (STEP bytes apart), (NP0,NP1) the first unit of whatever
+// follows.  The sched_barriers pin "loads first, then the MFMAs" and keep later units' loads from being
+// hoisted (which would blow the register budget).
+#define UNIT_(C0, C1, BLOAD, AHEAD, ANEXT, NA0, NA1, LO, ACUR, BCUR)                                      \
+    LOADB2(BLOAD, AHEAD) LOADA(ANEXT, (NA0), (NA1), LO) __builtin_amdgcn_sched_barrier(0);                \
+    SLAB_MFMA6(C0, C1, ACUR, BCUR) __builtin_amdgcn_sched_barrier(0);
+#define GROUP4H(C0, C1, P0, P1, NP0, NP1, STEP, LO)                                                        \
+    { UNIT_(C0, C1, B3, 3, A1_, (P0) + (STEP), (P1) + (STEP), LO, A0_, B0)                                 \
+      UNIT_(C0, C1, B0, 4, A0_, (P0) + 2 * (STEP), (P1) + 2 * (STEP), LO, A1_, B1)                         \
+      UNIT_(C0, C1, B1, 5, A1_, (P0) + 3 * (STEP), (P1) + 3 * (STEP), LO, A0_, B2)                         \
+      UNIT_(C0, C1, B2, 6, A0_, (NP0), (NP1), LO, A1_, B3)                                                 \
       bp += 4 * 128; }
+#define GROUP8H(C0, C1, PA0, PA1, PB0, PB1, NP0, NP1, STEP, LO)                                            \
+    { UNIT_(C0, C1, B7, 7,  A1_, (PA0) + (STEP), (PA1) + (STEP), LO, A0_, B0)                              \
+      UNIT_(C0, C1, B0, 8,  A0_, (PA0) + 2 * (STEP), (PA1) + 2 * (STEP), LO, A1_, B1)                      \
+      UNIT_(C0, C1, B1, 9,  A1_, (PA0) + 3 * (STEP), (PA1) + 3 * (STEP), LO, A0_, B2)                      \
+      UNIT_(C0, C1, B2, 10, A0_, (PB0), (PB1), LO, A1_, B3)                                                \
+      UNIT_(C0, C1, B3, 11, A1_, (PB0) + (STEP), (PB1) + (STEP), LO, A0_, B4)                              \
+      UNIT_(C0, C1, B4, 12, A0_, (PB0) + 2 * (STEP), (PB1) + 2 * (STEP), LO, A1_, B5)                      \
+      UNIT_(C0, C1, B5, 13, A1_, (PB0) + 3 * (STEP), (PB1) + 3 * (STEP), LO, A0_, B6)                      \
+      UNIT_(C0, C1, B6, 14, A0_, (NP0), (NP1), LO, A1_, B7)                                                \
+      bp += 8 * 128; }
 
 __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
@@ -256,18 +246,28 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
         f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
         {
             const f32x4 *bp = (const f32x4 *)R.ws1 + (size_t)wave * (S1_UNITS + SPF) * 128 + lane;
+            // conv1 carries two accumulator sets (scaled sum + unscaled partial), so its weight ring is 4 deep
             f32x4 B0[2], B1[2], B2[2], B3[2], A0_[4], A1_[4];
 #ifdef P2P_SPLIT_SKIP_CONV
             if (args.n < 0)     // never true: timing experiment without the MFMA loops
 #endif
             {
             LOADB2(B0, 0) LOADB2(B1, 1) LOADB2(B2, 2)
-            {   // level 0 of both images: 4 slabs per n-tile, already scaled -> straight into the accumulators
+            {   // level 0 of both images: 4 slabs, already scaled -> straight into the accumulators.  The
+                // stream interleaves the two n-tiles per slab here so that the group has its 8 units.
                 const unsigned char *p0 = smb + A0OFF + l31 * A0ST + half * 16;
                 const unsigned char *p1 = p0 + 32 * A0ST;
                 LOADA(A0_, p0, p1, A0PLANE)
-                GROUP4H(acc00, acc10, p0, p1, p0, p1, 32, A0PLANE)
-                GROUP4H(acc01, acc11, p0, p1, p0, p1, 32, A0PLANE)
+                UNIT_(acc00, acc10, B3, 3, A1_, p0, p1, A0PLANE, A0_, B0)
+                UNIT_(acc01, acc11, B0, 4, A0_, p0 + 32, p1 + 32, A0PLANE, A1_, B1)
+                UNIT_(acc00, acc10, B1, 5, A1_, p0 + 32, p1 + 32, A0PLANE, A0_, B2)
+                UNIT_(acc01, acc11, B2, 6, A0_, p0 + 64, p1 + 64, A0PLANE, A1_, B3)
+                bp += 4 * 128;
+                UNIT_(acc00, acc10, B3, 3, A1_, p0 + 64, p1 + 64, A0PLANE, A0_, B0)
+                UNIT_(acc01, acc11, B0, 4, A0_, p0 + 96, p1 + 96, A0PLANE, A1_, B1)
+                UNIT_(acc00, acc10, B1, 5, A1_, p0 + 96, p1 + 96, A0PLANE, A0_, B2)
+                UNIT_(acc01, acc11, B2, 6, A0_, p0, p1, A0PLANE, A1_, B3)
+                bp += 4 * 128;
             }
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
@@ -300,9 +300,10 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
                     for (int u = 0; u < 2; ++u) {
                         f32x16 t0 = {0}, t1 = {0};
                         LOADA(A0_, smb + ab[0][0], smb + ab[1][0], PLANE)
-                        GROUP4H(t0, t1, smb + ab[0][0], smb + ab[1][0], smb + ab[0][1], smb + ab[1][1], 32, PLANE)               // level 1
-                        GROUP4H(t0, t1, smb + ab[0][1], smb + ab[1][1], smb + ab[0][2], smb + ab[1][2], 32, PLANE)               // level 2
-                        GROUP4H(t0, t1, smb + ab[0][2], smb + ab[1][2], smb + ab[0][2] + 128, smb + ab[1][2] + 128, 32, PLANE)   // level 3
+                        // levels 1 and 2 (64 channels each), then level 3 (128 channels)
+                        GROUP4H(t0, t1, smb + ab[0][0], smb + ab[1][0], smb + ab[0][1], smb + ab[1][1], 32, PLANE)
+                        GROUP4H(t0, t1, smb + ab[0][1], smb + ab[1][1], smb + ab[0][2], smb + ab[1][2], 32, PLANE)
+                        GROUP4H(t0, t1, smb + ab[0][2], smb + ab[1][2], smb + ab[0][2] + 128, smb + ab[1][2] + 128, 32, PLANE)
                         GROUP4H(t0, t1, smb + ab[0][2] + 128, smb + ab[1][2] + 128, smb + ab[0][0], smb + ab[1][0], 32, PLANE)
                         // fold the unscaled partial sums in with the scale of the source pixel of each row
 #pragma unroll
@@ -352,9 +353,9 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
         // ------------------------------------------------------------ conv2: 3x3, stride 1, pad 1
         acc00 = (f32x16){0}; acc01 = (f32x16){0}; acc10 = (f32x16){0}; acc11 = (f32x16){0};
         {
-            const f32x4 *bp = (const f32x4 *)R.ws2 + (size_t)wave * (S2_SLABS + SPF) * 256 + lane;
-            f32x4 B0[4], B1[4], B2[4], B3[4], A0_[4], A1_[4];
-            LOADB(B0, 0) LOADB(B1, 1) LOADB(B2, 2)
+            const f32x4 *bp = (const f32x4 *)R.ws2 + (size_t)wave * (S2_UNITS + SPF) * 128 + lane;
+            f32x4 B0[2], B1[2], B2[2], B3[2], B4[2], B5[2], B6[2], B7[2], A0_[4], A1_[4];
+            LOADB2(B0, 0) LOADB2(B1, 1) LOADB2(B2, 2) LOADB2(B3, 3) LOADB2(B4, 4) LOADB2(B5, 5) LOADB2(B6, 6)
 #ifdef P2P_SPLIT_SKIP_CONV
             if (args.n < 0)
 #endif
@@ -367,11 +368,19 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
                 const bool ok1 = okx && (oy + 4 < 8);
                 const unsigned char *p0 = smb + (ok0 ? oy * 8 + ox : 64) * HPIX + half * 16;
                 const unsigned char *p1 = smb + (ok1 ? (oy + 4) * 8 + ox : 64) * HPIX + half * 16;
+                // one n-tile at a time: [tap][n-tile][32 slabs]
                 LOADA(A0_, p0, p1, HPLANE)
 #pragma unroll 1
-                for (int g = 0; g < 8; ++g) {
-                    const int gn = (g < 7) ? g + 1 : 7;      // the last group's look-ahead re-reads its own data
-                    GROUP4(acc00, acc01, acc10, acc11, p0 + g * 128, p1 + g * 128, p0 + gn * 128, p1 + gn * 128, 32, HPLANE)
+                for (int g = 0; g < 4; ++g) {
+                    const int gn = (g < 3) ? g + 1 : 0;
+                    GROUP8H(acc00, acc10, p0 + g * 256, p1 + g * 256, p0 + g * 256 + 128, p1 + g * 256 + 128,
+                            p0 + gn * 256, p1 + gn * 256, 32, HPLANE)
+                }
+#pragma unroll 1
+                for (int g = 0; g < 4; ++g) {
+                    const int gn = (g < 3) ? g + 1 : 3;
+                    GROUP8H(acc01, acc11, p0 + g * 256, p1 + g * 256, p0 + g * 256 + 128, p1 + g * 256 + 128,
+                            p0 + gn * 256, p1 + gn * 256, 32, HPLANE)
                 }
             }
         }
@@ -435,12 +444,12 @@ static void split_conv1_index(int slab, int half, int j, int &ch, int &tap) {
 
 void pack_split_weights(const float *conv1_w, const float *conv2_w, float *ws1, float *ws2) {
     uint16_t *d1 = (uint16_t *)ws1, *d2 = (uint16_t *)ws2;
-    // conv1 stream order per wave: level 0 [u][4 slabs], then [tap][img][u][16 slabs]; 2 KiB units [plane][lane][8]
+    // conv1 stream order per wave: level 0 [4 slabs][u], then [tap][img][u][16 slabs]; 2 KiB units [plane][lane][8]
     for (int w = 0; w < 8; ++w)
         for (int slab = 0; slab < S1_SLABS; ++slab)
             for (int u = 0; u < 2; ++u) {
                 int unit;
-                if (slab < 4) unit = u * 4 + slab;
+                if (slab < 4) unit = slab * 2 + u;      // level 0: the two n-tiles alternate
                 else { const int q = slab - 4; unit = 8 + ((q / 16) * 2 + u) * 16 + (q % 16); }
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
@@ -454,20 +463,23 @@ void pack_split_weights(const float *conv1_w, const float *conv2_w, float *ws1, 
                         d1[((base + 64 + lane) * 8) + j] = lo;
                     }
             }
+    // conv2 stream order per wave: [tap][u][32 slabs]
     for (int w = 0; w < 8; ++w)
         for (int slab = 0; slab < S2_SLABS; ++slab) {
             const int tap = slab / 32, sin = slab % 32;
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < 2; ++u) {
+                const int unit = (tap * 2 + u) * 32 + sin;
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
                         const int n = 64 * w + 32 * u + (lane & 31);
                         const int ch = sin * 16 + 8 * (lane >> 5) + j;
                         const float v = conv2_w[((size_t)n * 512 + ch) * 9 + tap];
                         const uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f(hi));
-                        const size_t base = ((((size_t)w * (S2_SLABS + SPF) + slab) * 2 + u) * 2) * 64;
+                        const size_t base = (((size_t)w * (S2_UNITS + SPF) + unit) * 2) * 64;
                         d2[((base + lane) * 8) + j] = hi;
                         d2[((base + 64 + lane) * 8) + j] = lo;
                     }
+            }
         }
 }
 
