@@ -299,7 +299,11 @@ __global__ __launch_bounds__(256) void nc_layer1_kernel(const float *__restrict_
 // staged (3 x (tb+2) x (tc+2) rows with halo, row stride 8*tdr+4 floats so that ds_read_b128 stays
 // 16-B aligned); at ~44 KB per work-group three of them share a CU and overlap each other's loads.
 struct NcTile { int tb, tc, tdr, rs; };
+constexpr int NC_MAX_ITERS = 12;      // FULLROW staging: wave instructions per channel stage (3*(tb+2)*(tc+2) rows / (4*rpi))
 
+// FULLROW: the tile spans the whole last axis (one d-tile, d3 % 4 == 0): rows are staged with 16-byte
+// loads, several rows per wave instruction, all of a stage's loads in flight at once.
+template <bool FULLROW>
 __global__ __launch_bounds__(256) void nc_layer2_kernel(const float *__restrict__ H1, Vol v, NcTile t,
                                                         const float *__restrict__ w2cat, float b2,
                                                         float *__restrict__ Y) {
@@ -333,6 +337,14 @@ __global__ __launch_bounds__(256) void nc_layer2_kernel(const float *__restrict_
     }
     const int colid = d0 + lane - 1;
     const bool colok = lane < ncol && colid >= 0 && colid < v.d3;
+    // FULLROW staging geometry: lpr lanes x float4 per row, rpi rows per wave instruction
+    const int lpr = v.d3 >> 2, rpi = 64 / max(lpr, 1);
+    const int myr = lane / max(lpr, 1), myq = lane - myr * lpr;
+    const bool lane_ok = myr < rpi;
+    const int niter = (nrows + 4 * rpi - 1) / (4 * rpi);
+    if (FULLROW) {      // the two halo columns are outside the volume: zero once, never overwritten
+        for (int r = tid; r < nrows; r += 256) { tile2[r * t.rs] = 0.f; tile2[r * t.rs + v.d3 + 1] = 0.f; }
+    }
     const int slab_c = t.rs, slab_b = hc * t.rs, slab_a = hb * hc * t.rs;
     const float *mybase = tile2 + (rb * hc + rc) * t.rs + 8 * rr;
 
@@ -343,6 +355,23 @@ __global__ __launch_bounds__(256) void nc_layer2_kernel(const float *__restrict_
         for (int ch = 0; ch < 16; ++ch) {
             const float *src = H1 + (size_t)(branch * 16 + ch) * nAB;
             __syncthreads();
+            if (FULLROW) {
+                f32x4 vals[NC_MAX_ITERS];
+#pragma unroll
+                for (int i = 0; i < NC_MAX_ITERS; ++i) {
+                    const int r = (i * 4 + wave) * rpi + myr;
+                    const int off = (i < niter && lane_ok && r < nrows) ? rowoff[r] : -1;
+                    vals[i] = (off >= 0) ? *(const f32x4 *)(src + off + 4 * myq) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int i = 0; i < NC_MAX_ITERS; ++i) {
+                    const int r = (i * 4 + wave) * rpi + myr;
+                    if (i < niter && lane_ok && r < nrows) {
+                        float *dst = tile2 + r * t.rs + 1 + 4 * myq;
+                        dst[0] = vals[i][0]; dst[1] = vals[i][1]; dst[2] = vals[i][2]; dst[3] = vals[i][3];
+                    }
+                }
+            } else {
             // stage one channel: each wave copies whole rows (coalesced along the last axis), eight
             // rows in flight per wave so that the loads overlap
             for (int r0 = wave; r0 < nrows; r0 += 32) {
@@ -358,6 +387,7 @@ __global__ __launch_bounds__(256) void nc_layer2_kernel(const float *__restrict_
                     const int r = r0 + 4 * u;
                     if (r < nrows && lane < ncol) tile2[r * t.rs + lane] = vals[u];
                 }
+            }
             }
             __syncthreads();
             if (active) {
@@ -628,7 +658,13 @@ extern "C" int p2p_coarse_forward(const float *featA, const float *featB, int C,
     const NcTile nt = pick_nc_tile(v);
     const int ntiles2 = v.d0 * ceil_div(v.d1, nt.tb) * ceil_div(v.d2, nt.tc) * ceil_div(v.d3, 8 * nt.tdr);
     const size_t lds2 = (size_t)3 * (nt.tb + 2) * (nt.tc + 2) * (nt.rs + 1) * 4;
-    hipLaunchKernelGGL(nc_layer2_kernel, dim3(ntiles2), dim3(256), lds2, stream, H1, v, nt, ncn->w2cat, ncn->b2, Y);
+    const int lpr = v.d3 / 4, rows2 = 3 * (nt.tb + 2) * (nt.tc + 2);
+    const bool fullrow = (v.d3 % 4 == 0) && (8 * nt.tdr >= v.d3) && lpr >= 1 && lpr <= 64 &&
+                         ceil_div(rows2, 4 * (64 / lpr)) <= NC_MAX_ITERS;
+    if (fullrow)
+        hipLaunchKernelGGL(nc_layer2_kernel<true>, dim3(ntiles2), dim3(256), lds2, stream, H1, v, nt, ncn->w2cat, ncn->b2, Y);
+    else
+        hipLaunchKernelGGL(nc_layer2_kernel<false>, dim3(ntiles2), dim3(256), lds2, stream, H1, v, nt, ncn->w2cat, ncn->b2, Y);
     hipLaunchKernelGGL(colmax_kernel, mgrid, dim3(256), 0, stream, Y, nAc, nBc, ckey2);
     hipLaunchKernelGGL(rowmax_kernel, dim3(ceil_div(nAc, 4)), dim3(256), 0, stream, Y, nAc, nBc, rkey2);
     const size_t nel = (size_t)nAc * nBc;
