@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""Summarise rocprofv3 --pmc result databases (one per counter group) into text + the regress traffic json.
+usage: python tools/pmc_summary.py OUT_TXT OUT_JSON db1 db2 ..."""
+import json
+import sqlite3
+import sys
+
+
+def main(out_txt, out_json, dbs):
+    rows = {}
+    for path in dbs:
+        c = sqlite3.connect(path)
+        q = ("select kernel_name, counter_name, count(*), avg(value), avg(end-start) from counters_collection "
+             "group by kernel_name, counter_name")
+        for name, counter, n, val, dur in c.execute(q):
+            rows.setdefault(name.split("(")[0], {})[counter] = (n, val, dur)
+    lines = ["# rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline (one pass per group)",
+             "# per-dispatch averages; FETCH_SIZE/WRITE_SIZE in KiB as reported; duration in ns; SQ_* wave counters in quad-cycles",
+             "# gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE under-reports wide coalesced reads by 2x -> doubled in the json"]
+    for k, v in rows.items():
+        if "p2p::" in k:
+            lines.append(k)
+            for cn, (n, val, dur) in sorted(v.items()):
+                lines.append(f"    {cn:32s} n={n:4d} avg={val:.5g} avg_duration_ns={dur:.0f}")
+    open(out_txt, "w").write("\n".join(lines) + "\n")
+    for k, rg in rows.items():
+        if "regress" in k and "FETCH_SIZE" in rg and "GRBM_GUI_ACTIVE" in rg:
+            fetch = rg["FETCH_SIZE"][1] * 1024 * 2
+            write = rg.get("WRITE_SIZE", (0, 0, 0))[1] * 1024
+            act = rg["GRBM_GUI_ACTIVE"]
+            clk = act[1] / 8 / (act[2] * 1e-9) / 1e9
+            mf = rg["SQ_VALU_MFMA_BUSY_CYCLES"][1] / 1024 / (act[1] / 8) if "SQ_VALU_MFMA_BUSY_CYCLES" in rg else None
+            json.dump({"kernel": k.split("::")[-1], "proposals_per_launch": 2000,
+                       "launch": "2000 proposals (5 pairs x 400), 2 levels", "hbm_bytes_per_launch": fetch + write,
+                       "fetch_bytes_corrected_x2": fetch, "write_bytes": write, "effective_clock_ghz": clk,
+                       "mfma_busy_fraction": mf, "source": out_txt}, open(out_json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3:])
