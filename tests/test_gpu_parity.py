@@ -240,3 +240,69 @@ def test_batched_launch_equals_per_pair(dev, ops, weights):
         single = ops.regress(mid_w, fine_w, pyr1[i], pyr2[i], props[i])
         for k in ("matches1", "probs1", "matches2", "probs2"):
             assert torch.equal(outs[i][k], single[k]), (i, k)
+
+
+# ------------------------------------------------------------------------------------------ full sizes
+def test_coarse_full_size_vs_oracle(dev, ops, weights):
+    """BASELINE config 1/2 size (480x640, ksize 2): the whole coarse stage against the CPU oracle."""
+    sd, ncn, _, _ = weights
+    p1, p2 = synthetic.make_correlated_pyramids(77, 480, 640)
+    o_ncn, _, _ = orc.split_params(sd)
+    rc, rd = orc.coarse_forward(p1[4], p2[4], 2, o_ncn)
+    corr, delta = ops.coarse_forward(p1[4].to(dev), p2[4].to(dev), 2, ncn)
+    flips = _check_coarse(corr.cpu().numpy(), delta.cpu().numpy().astype(np.int64), rc.numpy(), [d.numpy() for d in rd], 2)
+    assert flips <= 4, f"{flips} of 1.44 M relocalisation argmaxes differ (near-ties)"
+    rm, rs = orc.cal_coarse_matches(rc, rd, 2, 8)
+    m, s = ops.coarse_matches(corr, delta, 2, 8, True)
+    same = (m.cpu() == rm).all(dim=1)
+    assert same.float().mean() > 0.995, f"only {same.float().mean():.4f} of the coarse matches agree"
+    assert torch.allclose(s.cpu()[same], rs[same], rtol=2e-4)
+
+
+@pytest.mark.parametrize("hw", [(480, 640), (960, 1280)])
+def test_coarse_symmetry_property(hw, dev, ops, weights):
+    """Size-independent property at the BASELINE sizes (config E = 960x1280: 1.5 GB full-resolution volume,
+    3 GB hidden layer): the consensus stage is symmetric by construction, so swapping the two images must
+    transpose the volume -- corr(A,B)[a,b,c,d] == corr(B,A)[c,d,a,b] -- and swap the two match directions."""
+    _, ncn, _, _ = weights
+    H, W = hw
+    p1, p2 = synthetic.make_correlated_pyramids(5, H, W)
+    fa, fb = p1[4].to(dev), p2[4].to(dev)
+    c_ab, d_ab = ops.coarse_forward(fa, fb, 2, ncn)
+    c_ab, d_ab = c_ab.clone(), d_ab.clone()
+    c_ba, d_ba = ops.coarse_forward(fb, fa, 2, ncn)
+    ref = c_ab.permute(2, 3, 0, 1)
+    assert torch.isfinite(c_ab).all()
+    rel = ((c_ba - ref).abs() / (ref.abs() + 1e-6)).max().item()
+    assert rel < 1e-3, rel
+    # relocalisation codes: (di,dj,dk,dl) of (A,B) == (dk,dl,di,dj) of (B,A) except on near-ties
+    s_ab = d_ab.permute(2, 3, 0, 1).long()
+    swapped = ((s_ab & 3) << 2) | (s_ab >> 2)
+    assert (swapped != d_ba.long()).float().mean().item() < 1e-4
+    m_ab, s1 = ops.coarse_matches(c_ab, d_ab, 2, 8, True)
+    assert (s1 > 0).all() and (s1 <= 1.0 + 1e-6).all()
+    assert (m_ab >= 4).all() and (m_ab[:, 0] < W).all() and (m_ab[:, 1] < H).all()
+
+
+def test_regress_is_deterministic_and_anchor_path(dev, ops, weights):
+    """Same launch twice -> bit-identical; config E style proposals (ptmax 800 x panc 8 = 6400) run through
+    shift_to_anchors semantics and agree with the oracle on a sample."""
+    sd, _, mid_w, fine_w = weights
+    H, W = 192, 256
+    p1 = synthetic.make_pyramid(11, H, W)
+    p2 = synthetic.make_pyramid(12, H, W)
+    g = torch.Generator().manual_seed(4)
+    base = torch.stack([torch.randint(8, W - 8, (800,), generator=g), torch.randint(8, H - 8, (800,), generator=g),
+                        torch.randint(8, W - 8, (800,), generator=g), torch.randint(8, H - 8, (800,), generator=g)], 1)
+    props = orc.shift_to_anchors(base, 8, 8)
+    assert props.shape == (6400, 4)
+    g1, g2 = _gpu(p1[:4], dev), _gpu(p2[:4], dev)
+    a = ops.regress(mid_w, fine_w, g1, g2, props.to(dev))
+    b = ops.regress(mid_w, fine_w, g1, g2, props.to(dev))
+    for k in ("matches1", "matches2", "probs1", "probs2"):
+        assert torch.equal(a[k], b[k])
+    _, mid_p, _ = orc.split_params(sd)
+    idx = torch.arange(0, 6400, 97)
+    ref_mid, ref_p, _ = orc.fine_level(p1[:4], p2[:4], props[idx], mid_p)
+    _compare_matches(a["matches1"].cpu()[idx], ref_mid)
+    assert (a["probs1"].cpu()[idx] - ref_p).abs().max() <= SCORE_TOL
