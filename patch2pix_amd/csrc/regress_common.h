@@ -45,16 +45,22 @@ __device__ __forceinline__ int patch_cell(int origin, int p, int j, int dim) {
 __device__ __forceinline__ void fc_tail_parse(const RegDev &R, const ItemDev &I, const RegressArgs &args, int lvl, int prop,
                                               int tid, const float *V, float *F1, float *F2, float *misc) {
     asm volatile("" : "+v"(tid));      // keep the per-lane weight offsets from being hoisted out of the level loop (and spilled)
-    {
+    {   // 512 outputs x 512 inputs: 32 weight loads (16 B each) in flight per thread
         const f32x4 *w = (const f32x4 *)R.fc1t + tid;
         float s = 0.f;
-#pragma unroll 8
-        for (int kq = 0; kq < 128; ++kq) {
-            f32x4 wv = w[kq * 512];
-            s = fmaf(wv[0], V[4 * kq + 0], s);
-            s = fmaf(wv[1], V[4 * kq + 1], s);
-            s = fmaf(wv[2], V[4 * kq + 2], s);
-            s = fmaf(wv[3], V[4 * kq + 3], s);
+#pragma unroll 1
+        for (int k0 = 0; k0 < 128; k0 += 32) {
+            f32x4 wv[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) wv[i] = w[(k0 + i) * 512];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const f32x4 x = *(const f32x4 *)(V + 4 * (k0 + i));
+                s = fmaf(wv[i][0], x[0], s);
+                s = fmaf(wv[i][1], x[1], s);
+                s = fmaf(wv[i][2], x[2], s);
+                s = fmaf(wv[i][3], x[3], s);
+            }
         }
         s += R.fc1b[tid];
         F1[tid] = fmaxf(fmaf(s, R.bnf1s[tid], R.bnf1b[tid]), 0.f);
@@ -63,22 +69,41 @@ __device__ __forceinline__ void fc_tail_parse(const RegDev &R, const ItemDev &I,
     if (tid < 256) {
         const f32x4 *w = (const f32x4 *)R.fc2t + tid;
         float s = 0.f;
-#pragma unroll 8
-        for (int kq = 0; kq < 128; ++kq) {
-            f32x4 wv = w[kq * 256];
-            s = fmaf(wv[0], F1[4 * kq + 0], s);
-            s = fmaf(wv[1], F1[4 * kq + 1], s);
-            s = fmaf(wv[2], F1[4 * kq + 2], s);
-            s = fmaf(wv[3], F1[4 * kq + 3], s);
+#pragma unroll 1
+        for (int k0 = 0; k0 < 128; k0 += 32) {
+            f32x4 wv[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) wv[i] = w[(k0 + i) * 256];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const f32x4 x = *(const f32x4 *)(F1 + 4 * (k0 + i));
+                s = fmaf(wv[i][0], x[0], s);
+                s = fmaf(wv[i][1], x[1], s);
+                s = fmaf(wv[i][2], x[2], s);
+                s = fmaf(wv[i][3], x[3], s);
+            }
         }
         s += R.fc2b[tid];
         F2[tid] = fmaxf(fmaf(s, R.bnf2s[tid], R.bnf2b[tid]), 0.f);
     }
     __syncthreads();
     if (tid < 5) {
-        const float *w = R.fc3 + tid * 256;
+        const f32x4 *w = (const f32x4 *)(R.fc3 + tid * 256);
         float s = 0.f;
-        for (int k = 0; k < 256; ++k) s = fmaf(w[k], F2[k], s);
+#pragma unroll 1
+        for (int k0 = 0; k0 < 64; k0 += 16) {
+            f32x4 wv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) wv[i] = w[k0 + i];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const f32x4 x = *(const f32x4 *)(F2 + 4 * (k0 + i));
+                s = fmaf(wv[i][0], x[0], s);
+                s = fmaf(wv[i][1], x[1], s);
+                s = fmaf(wv[i][2], x[2], s);
+                s = fmaf(wv[i][3], x[3], s);
+            }
+        }
         s += R.fc3b[tid];
         misc[tid] = s;
         if (args.raw[lvl]) args.raw[lvl][(size_t)prop * 5 + tid] = s;

@@ -162,6 +162,9 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
             for (int q = 0; q < nb; q += 16) *(f32x4 *)(z + q) = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         // ------------------------------------------------------------ gather (networks/utils.py:4-36)
+#ifdef P2P_SPLIT_SKIP_GATHER
+        if (args.n < 0)
+#endif
         for (int img = 0; img < 2; ++img) {
             const int Hh = I.H[img], Ww = I.W[img];
             {   // level 0: raw fp32 [3][16x16]
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
                 const int r0 = clampi(Y0(img) >> j, 0, Hj - 1);
                 const int c0 = clampi(X0(img) >> j, 0, Wj - 1);
                 const float *src = I.pyr[img][j];
-#pragma unroll 4
+#pragma unroll 8
                 for (int e = tidv; e < Cc * Rr * Rr; e += NT) {
                     const int c = e / (Rr * Rr);
                     const int rem = e - c * (Rr * Rr);
@@ -323,6 +326,9 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
         __syncthreads();   // all waves are done reading the conv1 operands
 
         // BN1 -> split -> H[pixel][channel] (bf16 hi / lo planes), plus the all-zero padding row
+#ifdef P2P_SPLIT_SKIP_HWRITE
+        if (args.n < 0)
+#endif
         {
             if (tid < 2 * (HPIX / 16)) {
                 const int plane = tid / (HPIX / 16), q = tid - plane * (HPIX / 16);
@@ -405,6 +411,9 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
         }
         __syncthreads();
 
+#ifdef P2P_SPLIT_SKIP_FC
+        if (args.n < 0)
+#endif
         fc_tail_parse(R, I, args, lvl, prop, tid, V, F1, F2, misc);
     }
 }

@@ -306,3 +306,60 @@ def test_regress_is_deterministic_and_anchor_path(dev, ops, weights):
     ref_mid, ref_p, _ = orc.fine_level(p1[:4], p2[:4], props[idx], mid_p)
     _compare_matches(a["matches1"].cpu()[idx], ref_mid)
     assert (a["probs1"].cpu()[idx] - ref_p).abs().max() <= SCORE_TOL
+
+
+def test_nc_only_model_and_predict_coarse(dev, tmp_path):
+    """load_model(method='nc') (bare NCNet state_dict, model_helper.py:53-57) + predict_coarse /
+    estimate_matches(eval_type='coarse') against the oracle's coarse stage on CPU-computed pyramids."""
+    from patch2pix_amd.utils.eval import model_helper
+    sd = gu.state_dict(0)
+    nc_sd = {k: v for k, v in sd.items() if k.startswith(("extract.", "ncn."))}
+    net = model_helper.load_model({"state_dict": nc_sd}, method="nc", lprint=lambda *a: None)
+    assert net.regress_mid is None and net.upsample == 8
+    g = gu.load("coarse_128x160_k2")
+    p1, p2 = gu.coarse_inputs(g)
+    corr4d, delta4d = net.forward_coarse_match(p1[4][None].to(dev), p2[4][None].to(dev), ksize=2)
+    assert corr4d.shape == (1, 1, 8, 10, 8, 10) and len(delta4d) == 4
+    assert delta4d[0].dtype == torch.int64 and delta4d[0].shape == corr4d.shape
+    m, s = net.cal_coarse_matches(corr4d, delta4d, ksize=2, upsample=net.upsample, center=True)
+    assert np.array_equal(m[0].cpu().numpy(), g["all_matches"])
+    # the reference-format delta4d (four int64 planes) is accepted as well as the packed form
+    planes = tuple(t.clone() for t in delta4d)
+    m2, _ = net.cal_coarse_matches(corr4d, planes, ksize=2, upsample=net.upsample, center=True)
+    assert torch.equal(m, m2)
+    from patch2pix_amd.networks.utils import filter_coarse
+    fm, fs = filter_coarse(m, s, 0.0, True)
+    assert np.array_equal(fm[0].cpu().numpy(), g["mutual_matches"])
+    fu, _ = filter_coarse(m, s, 0.0, False)
+    assert np.array_equal(fu[0].cpu().numpy(), g["unique_matches"])
+    # sort=True orders by descending score
+    ms, ss = net.cal_coarse_matches(corr4d, delta4d, ksize=2, upsample=net.upsample, sort=True)
+    assert (ss[0][:-1] >= ss[0][1:]).all()
+
+
+def test_batch_of_pairs_through_model(dev):
+    """B = 3 pairs through predict_fine_from_feats == the three pairs one at a time (lists per batch item)."""
+    net = _model(dev)
+    pairs = [synthetic.make_correlated_pyramids(60 + i, 128, 160) for i in range(3)]
+    f1 = [torch.stack([p[0][j] for p in pairs]).to(dev) for j in range(5)]
+    f2 = [torch.stack([p[1][j] for p in pairs]).to(dev) for j in range(5)]
+    fine, scores, coarse = net.predict_fine_from_feats(f1, f2)
+    assert len(fine) == len(scores) == len(coarse) == 3
+    for b in range(3):
+        one = net.predict_fine_from_feats([t[b:b + 1] for t in f1], [t[b:b + 1] for t in f2])
+        assert torch.equal(coarse[b], one[2][0])
+        assert torch.equal(fine[b], one[0][0]) and torch.equal(scores[b], one[1][0])
+
+
+def test_refine_matches_and_empty_input(dev):
+    net = _model(dev)
+    im1, im2 = synthetic.make_image_pair(9, 96, 128)
+    t1 = torch.from_numpy(im1).permute(2, 0, 1).float().div(255)[None].to(dev)
+    t2 = torch.from_numpy(im2).permute(2, 0, 1).float().div(255)[None].to(dev)
+    r, s, c = net.refine_matches(t1, t2, np.zeros((0, 4)), 0.25)
+    assert r.shape == (0, 4) and s.shape == (0,) and c.shape == (0, 4)
+    coarse = np.array([[20, 20, 28, 36], [60, 44, 68, 60], [100, 80, 92, 72]], dtype=np.int64)
+    with torch.no_grad():
+        r, s, c = net.refine_matches(t1, t2, coarse, 0.0)
+    assert r.shape == (3, 4) and s.shape == (3,) and np.array_equal(c, coarse)
+    assert np.isfinite(r).all() and (np.abs(r - coarse) <= 16.0 + 1e-3).all()
