@@ -37,9 +37,9 @@ ISSUED_BF16_FLOP_PER_PROPOSAL_LEVEL = 8 * (584 + 576) * 6 * 32768
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs-per-step", type=int, default=5,
+    ap.add_argument("--pairs-per-step", type=int, default=16,
                     help="image pairs per step; their proposals share one regress launch (fills the 256 CUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()

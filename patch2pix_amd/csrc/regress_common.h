@@ -5,7 +5,7 @@
 namespace p2p {
 
 constexpr int NT = 512;                 // threads per workgroup (8 waves)
-constexpr int MAXB = 8;                 // image pairs per launch
+constexpr int MAXB = 16;                // image pairs per launch
 
 struct RegDev {
     const float *wp1, *wp2;             // f32 MFMA-fragment order (regress.hip)

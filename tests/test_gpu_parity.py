@@ -225,13 +225,14 @@ def test_batched_launch_equals_per_pair(dev, ops, weights):
     """p2p_regress_batch over pairs of *different* sizes == one launch per pair (bit-exact),
     including an empty item and more items than one launch holds."""
     _, _, mid_w, fine_w = weights
-    sizes = [(48, 64), (96, 128), (64, 48), (48, 64), (80, 80), (48, 64), (96, 64), (64, 64), (48, 96), (56, 72)]
+    sizes = [(48, 64), (96, 128), (64, 48), (48, 64), (80, 80), (48, 64), (96, 64), (64, 64), (48, 96), (56, 72),
+             (48, 64), (64, 96), (72, 56), (48, 48), (88, 64), (64, 80), (48, 72), (56, 56)]   # 18 > 16 items per launch
     g = torch.Generator().manual_seed(3)
     pyr1, pyr2, props = [], [], []
     for i, (H, W) in enumerate(sizes):
         pyr1.append(_gpu(synthetic.make_pyramid(200 + i, H, W)[:4], dev))
         pyr2.append(_gpu(synthetic.make_pyramid(300 + i, H, W)[:4], dev))
-        n = 0 if i == 3 else 5 + 3 * i
+        n = 0 if i == 3 else 5 + (3 * i) % 17
         props.append(torch.stack([torch.randint(0, W + 1, (n,), generator=g), torch.randint(0, H + 1, (n,), generator=g),
                                   torch.randint(0, W + 1, (n,), generator=g), torch.randint(0, H + 1, (n,), generator=g)],
                                  1).to(dev))
