@@ -348,6 +348,22 @@ __global__ __launch_bounds__(256) void nc_layer2_kernel(const float *__restrict_
     const int slab_c = t.rs, slab_b = hc * t.rs, slab_a = hb * hc * t.rs;
     const float *mybase = tile2 + (rb * hc + rc) * t.rs + 8 * rr;
 
+    // FULLROW: the rows of hidden channel ch+1 are fetched into registers (16-byte loads, all in flight) while
+    // channel ch is convolved out of LDS, and written to LDS after the barrier that ends that compute.
+    f32x4 vals[NC_MAX_ITERS];
+    auto fetch = [&](int chn) {
+        const float *src = H1 + (size_t)chn * nAB;
+#pragma unroll
+        for (int i = 0; i < NC_MAX_ITERS; ++i) {
+            const int r = (i * 4 + wave) * rpi + myr;
+            const int off = (i < niter && lane_ok && r < nrows) ? rowoff[r] : -1;
+            vals[i] = (off >= 0) ? *(const f32x4 *)(src + off + 4 * myq) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    if (FULLROW) {
+        __syncthreads();        // rowoff / halo zeros are ready
+        fetch(0);
+    }
     for (int branch = 0; branch < 2; ++branch) {
         float acc[8];
 #pragma unroll
@@ -356,13 +372,6 @@ __global__ __launch_bounds__(256) void nc_layer2_kernel(const float *__restrict_
             const float *src = H1 + (size_t)(branch * 16 + ch) * nAB;
             __syncthreads();
             if (FULLROW) {
-                f32x4 vals[NC_MAX_ITERS];
-#pragma unroll
-                for (int i = 0; i < NC_MAX_ITERS; ++i) {
-                    const int r = (i * 4 + wave) * rpi + myr;
-                    const int off = (i < niter && lane_ok && r < nrows) ? rowoff[r] : -1;
-                    vals[i] = (off >= 0) ? *(const f32x4 *)(src + off + 4 * myq) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
 #pragma unroll
                 for (int i = 0; i < NC_MAX_ITERS; ++i) {
                     const int r = (i * 4 + wave) * rpi + myr;
@@ -375,21 +384,22 @@ __global__ __launch_bounds__(256) void nc_layer2_kernel(const float *__restrict_
             // stage one channel: each wave copies whole rows (coalesced along the last axis), eight
             // rows in flight per wave so that the loads overlap
             for (int r0 = wave; r0 < nrows; r0 += 32) {
-                float vals[8];
+                float v8[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int r = r0 + 4 * u;
                     const int off = (r < nrows) ? rowoff[r] : -1;
-                    vals[u] = (off >= 0 && colok) ? src[off + colid] : 0.f;
+                    v8[u] = (off >= 0 && colok) ? src[off + colid] : 0.f;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int r = r0 + 4 * u;
-                    if (r < nrows && lane < ncol) tile2[r * t.rs + lane] = vals[u];
+                    if (r < nrows && lane < ncol) tile2[r * t.rs + lane] = v8[u];
                 }
             }
             }
             __syncthreads();
+            if (FULLROW && branch * 16 + ch + 1 < 32) fetch(branch * 16 + ch + 1);
             if (active) {
                 const float *wch = w2cat + (branch * 16 + ch) * 81;
                 for (int da = 0; da < 3; ++da)
