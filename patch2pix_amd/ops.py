@@ -34,7 +34,7 @@ class NcnWeights:
         self.device = torch.device(device)
 
     def __del__(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and _lib is not None:      # _lib is None during interpreter shutdown
             _lib.p2p_ncn_destroy(self.handle)
             self.handle = None
 
@@ -77,7 +77,7 @@ class RegressorWeights:
         return {v: k for k, v in _lib.REGRESS_MODES.items()}[code]
 
     def __del__(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and _lib is not None:
             _lib.p2p_regressor_destroy(self.handle)
             self.handle = None
 
