@@ -84,6 +84,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # host side of a rank is one Python thread plus small torch-CPU ops: keep N ranks from oversubscribing the host
+    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // max(world, 1))))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
