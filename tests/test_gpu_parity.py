@@ -364,3 +364,32 @@ def test_refine_matches_and_empty_input(dev):
         r, s, c = net.refine_matches(t1, t2, coarse, 0.0)
     assert r.shape == (3, 4) and s.shape == (3,) and np.array_equal(c, coarse)
     assert np.isfinite(r).all() and (np.abs(r - coarse) <= 16.0 + 1e-3).all()
+
+
+def test_images_of_different_sizes(dev, ops, weights):
+    """Ragged pair: image 1 is 64x96, image 2 is 96x64 (the volume is 4x6 x 6x4 cells, not square)."""
+    sd, ncn, mid_w, fine_w = weights
+    p1 = synthetic.make_pyramid(71, 64, 96)
+    p2 = synthetic.make_pyramid(72, 96, 64)
+    o_ncn, mid_p, _ = orc.split_params(sd)
+    for ksize in (1, 2):
+        rc, rd = orc.coarse_forward(p1[4], p2[4], ksize, o_ncn)
+        corr, delta = ops.coarse_forward(p1[4].to(dev), p2[4].to(dev), ksize, ncn)
+        assert tuple(corr.shape) == tuple(rc.shape)
+        flips = _check_coarse(corr.cpu().numpy(), None if delta is None else delta.cpu().numpy().astype(np.int64),
+                              rc.numpy(), None if rd is None else [d.numpy() for d in rd], ksize)
+        assert flips == 0
+        rm, rs = orc.cal_coarse_matches(rc, rd, ksize, 8)
+        m, s = ops.coarse_matches(corr, delta, ksize, 8, True)
+        assert torch.equal(m.cpu(), rm) and torch.allclose(s.cpu(), rs, rtol=2e-4)
+    g = torch.Generator().manual_seed(1)
+    n = 21
+    props = torch.stack([torch.randint(0, 97, (n,), generator=g), torch.randint(0, 65, (n,), generator=g),
+                         torch.randint(0, 65, (n,), generator=g), torch.randint(0, 97, (n,), generator=g)], 1)
+    ref_mid, ref_p, _ = orc.fine_level(p1[:4], p2[:4], props, mid_p)
+    out = ops.regress(mid_w, None, _gpu(p1[:4], dev), _gpu(p2[:4], dev), props.to(dev))
+    _compare_matches(out["matches1"].cpu(), ref_mid)
+    assert (out["probs1"].cpu() - ref_p).abs().max() <= SCORE_TOL
+    # clamping uses each image's own size: x1 <= 96, y1 <= 64, x2 <= 64, y2 <= 96
+    hi = torch.tensor([96.0, 64.0, 64.0, 96.0])
+    assert (out["matches1"].cpu() <= hi).all() and (out["matches1"].cpu() >= 0).all()
