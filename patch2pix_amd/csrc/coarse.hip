@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void nc_layer2_kernel(const float *__restrict_
     const int hb = t.tb + 2, hc = t.tc + 2, ncol = td + 2;
     const int nrows = 3 * hb * hc;
     // this thread's run of 8 outputs
-    const int rr = tid % t.tdr, rc = (tid / t.tdr) % t.tc, rb = tid / (t.tdr * t.tc);
+    const int rc = tid % t.tc, rr = (tid / t.tc) % t.tdr, rb = tid / (t.tdr * t.tc);   // rows fastest: fewer LDS bank conflicts
     const bool active = rb < t.tb;
     float out[8];
 #pragma unroll
@@ -437,16 +437,16 @@ __global__ __launch_bounds__(256) void nc_layer2_kernel(const float *__restrict_
 
 // tile shape with the least padding for this volume (<= 256 runs, <= 52 KB of LDS so 3 groups fit a CU)
 static NcTile pick_nc_tile(const Vol &v) {
-    NcTile best{4, 8, 4, 36};
+    NcTile best{4, 8, 4, 44};
     double best_eff = -1;
     const int tbs[] = {2, 3, 4, 5, 6, 8}, tcs[] = {4, 5, 6, 8, 10, 12, 15, 16}, tdrs[] = {2, 3, 4, 5, 6, 7};   // 8*tdr+2 columns must fit one wave
     for (int tdr : tdrs)
         for (int tb : tbs)
             for (int tc : tcs) {
                 if (tb * tc * tdr > 256) continue;
-                const int rs = 8 * tdr + 4;
+                const int rs = 8 * tdr + 12;   // 52 words for 40-wide rows: best of the multiples of 4 for ds_read_b128 (bank model)
                 const size_t lds = (size_t)3 * (tb + 2) * (tc + 2) * (rs + 1) * 4;
-                if (lds > 52 * 1024) continue;
+                if (lds > 54000) continue;                 // three groups per CU (160 KiB)
                 const double groups = (double)v.d0 * ceil_div(v.d1, tb) * ceil_div(v.d2, tc) * ceil_div(v.d3, 8 * tdr);
                 const double useful = (double)v.d0 * v.d1 * v.d2 * v.d3;
                 // padding efficiency x halo efficiency (staged cells per useful output)
