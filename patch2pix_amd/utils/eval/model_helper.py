@@ -1,7 +1,17 @@
-"""Drop-in for reference utils/eval/model_helper.py: `load_model`, `estimate_matches`,
-`init_patch2pix_matcher`, `init_ncn_matcher` with identical signatures and return layouts
-(float64 [M,4] matches in original-image pixels, float32 [M] scores, float64 [M,4] coarse)."""
+"""Entry points of the matching path with the reference's names and contracts.
+
+Role of reference utils/eval/model_helper.py: `load_model(ckpt_path, method, lprint)`,
+`estimate_matches(net, im1, im2, ksize, ncn_thres, mutual, io_thres, eval_type, imsize)` and the two matcher
+factories `init_patch2pix_matcher(args)` / `init_ncn_matcher(args)`.  Signatures, defaults and return layouts are the
+reference's (what image-matching-toolbox binds to); the bodies are organised around the HIP library underneath.
+
+Return contract of `estimate_matches` (reference :64-109):
+    matches         float64 [M,4]  (x1, y1, x2, y2) in ORIGINAL image pixels
+    scores          float32 [M]
+    coarse_matches  float64 [M,4]  the coarse match each row was refined from (same as matches for eval_type='coarse')
+"""
 from argparse import Namespace
+from functools import partial
 
 import numpy as np
 import torch
@@ -10,75 +20,104 @@ from ..common.setup_helper import load_weights
 from ..datasets.preprocess import load_im_flexible
 from ...networks.patch2pix import Patch2Pix
 
+_SILENT = lambda *a, **k: None
+
+
+# ------------------------------------------------------------------------------------------ model construction
+def _base_config(device):
+    """Inference configuration of reference :32-39 (change_stride on, proposals in chunks of 1200)."""
+    return Namespace(device=device, training=False, backbone="ResNet34", change_stride=True, regr_batch=1200,
+                     feat_idx=None, regressor_config=None, weights_dict=None)
+
+
+def _configure_patch2pix(config, ckpt):
+    """A full checkpoint (utils/train/helper.py:10-20) carries its own architecture description."""
+    for field in ("backbone", "feat_idx", "regressor_config"):
+        setattr(config, field, ckpt[field])
+    config.weights_dict = ckpt["state_dict"]
+    config.regressor_config.panc = 1          # evaluation never expands anchors (reference :46)
+
+
+def _configure_ncn(config, ckpt):
+    """NCNet-only checkpoints are a bare state_dict or {'state_dict': ...} (reference :53-57)."""
+    config.weights_dict = ckpt["state_dict"] if isinstance(ckpt, dict) and "state_dict" in ckpt else ckpt
+
+
+def load_model(ckpt_path, method="patch2pix", lprint=print):
+    """Build the network on the current HIP device and load a reference-format checkpoint.
+    `ckpt_path` may also be an already loaded checkpoint dict."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("patch2pix_amd needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    device = torch.device("cuda", torch.cuda.current_device())
+    in_memory = isinstance(ckpt_path, dict)
+    ckpt = ckpt_path if in_memory else load_weights(ckpt_path, device)
+    config = _base_config(device)
+    lprint("\nLoad model method:{} ".format(method))
+    if "patch2pix" in method:
+        _configure_patch2pix(config, ckpt)
+        origin = "<in-memory checkpoint>" if in_memory else ckpt_path
+        lprint(f"Ckpt:{origin} epochs:{ckpt['last_epoch'] + 1}" if "last_epoch" in ckpt else f"Ckpt:{origin}")
+    elif "nc" in method:
+        _configure_ncn(config, ckpt)
+        lprint("Load pretrained weights: {}".format("<in-memory checkpoint>" if in_memory else ckpt_path))
+    else:
+        lprint("Wrong method name.")
+    return Patch2Pix(config).eval()
+
 
 def init_patch2pix_matcher(args):
     net = load_model(args.ckpt, method="patch2pix")
-    return lambda imq, imr: estimate_matches(net, imq, imr, ksize=args.ksize, io_thres=args.io_thres,
-                                             eval_type="fine", imsize=args.imsize)
+    return partial(_call_fine, net, args)
 
 
 def init_ncn_matcher(args):
     net = load_model(args.ckpt, method="nc")
-    return lambda imq, imr: estimate_matches(net, imq, imr, ksize=args.ksize, ncn_thres=args.ncn_thres,
-                                             eval_type="coarse", imsize=args.imsize)
+    return partial(_call_coarse, net, args)
 
 
-def load_model(ckpt_path, method="patch2pix", lprint=print):
-    """model_helper.py:28-62.  The device is cuda:<current> -- this package has no CPU path."""
-    if not torch.cuda.is_available():
-        raise RuntimeError("patch2pix_amd needs an MI355X (torch.cuda.is_available() is False)")
-    device = torch.device("cuda:{}".format(torch.cuda.current_device()))
-    ckpt = ckpt_path if isinstance(ckpt_path, dict) else load_weights(ckpt_path, device)
-    config = Namespace(training=False, device=device, regr_batch=1200, backbone="ResNet34", feat_idx=None,
-                       weights_dict=None, regressor_config=None, change_stride=True)
-    lprint("\nLoad model method:{} ".format(method))
-    if "patch2pix" in method:
-        config.backbone = ckpt["backbone"]
-        config.feat_idx = ckpt["feat_idx"]
-        config.weights_dict = ckpt["state_dict"]
-        config.regressor_config = ckpt["regressor_config"]
-        config.regressor_config.panc = 1          # evaluation always uses panc 1 (model_helper.py:46)
-        if "last_epoch" in ckpt:
-            lprint(f"Ckpt:{ckpt_path if not isinstance(ckpt_path, dict) else '<dict>'} epochs:{ckpt['last_epoch'] + 1}")
-    elif "nc" in method:
-        if isinstance(ckpt, dict) and "state_dict" in ckpt:
-            ckpt = ckpt["state_dict"]
-        config.weights_dict = ckpt
-    else:
-        lprint("Wrong method name.")
-    net = Patch2Pix(config)
-    net.eval()
-    return net
+def _call_fine(net, args, imq, imr):
+    return estimate_matches(net, imq, imr, ksize=args.ksize, io_thres=args.io_thres, eval_type="fine", imsize=args.imsize)
+
+
+def _call_coarse(net, args, imq, imr):
+    return estimate_matches(net, imq, imr, ksize=args.ksize, ncn_thres=args.ncn_thres, eval_type="coarse",
+                            imsize=args.imsize)
+
+
+# ------------------------------------------------------------------------------------------ matching
+def _load_pair(net, im1, im2, ksize, imsize):
+    """Both images as [1,3,H,W] tensors on the device + the (1,4) factors back to original pixels."""
+    tensors, factors = [], ()
+    for im in (im1, im2):
+        t, scale_wh = load_im_flexible(im, ksize, net.upsample, imsize=imsize)
+        tensors.append(t.unsqueeze(0).to(net.device))
+        factors += tuple(scale_wh)
+    return tensors[0], tensors[1], np.array([factors])
+
+
+def _host(t):
+    return t.detach().cpu().numpy()
 
 
 def estimate_matches(net, im1, im2, ksize=2, ncn_thres=0.0, mutual=True, io_thres=0.25, eval_type="fine",
                      imsize=None):
-    """model_helper.py:64-109 (batch size 1)."""
-    im1, sc1 = load_im_flexible(im1, ksize, net.upsample, imsize=imsize)
-    im2, sc2 = load_im_flexible(im2, ksize, net.upsample, imsize=imsize)
-    upscale = np.array([sc1 + sc2])
-    im1 = im1.unsqueeze(0).to(net.device)
-    im2 = im2.unsqueeze(0).to(net.device)
+    """Match one image pair (batch size 1, like the reference)."""
+    t1, t2, to_original = _load_pair(net, im1, im2, ksize, imsize)
 
     if eval_type == "coarse":
         with torch.no_grad():
-            coarse_matches, scores = net.predict_coarse(im1, im2, ksize=ksize, ncn_thres=ncn_thres, mutual=mutual)
-        matches = upscale * coarse_matches[0].cpu().data.numpy()
-        return matches, scores[0].cpu().data.numpy(), matches
+            rows, row_scores = net.predict_coarse(t1, t2, ksize=ksize, ncn_thres=ncn_thres, mutual=mutual)
+        pixels = to_original * _host(rows[0])
+        return pixels, _host(row_scores[0]), pixels
 
-    if eval_type == "fine":
-        with torch.no_grad():
-            fine_matches, fine_scores, coarse_matches = net.predict_fine(im1, im2, ksize=ksize, ncn_thres=ncn_thres,
-                                                                         mutual=mutual)
-        coarse_matches = coarse_matches[0].cpu().data.numpy()
-        fine_matches = fine_matches[0].cpu().data.numpy()
-        fine_scores = fine_scores[0].cpu().data.numpy()
+    if eval_type != "fine":
+        raise ValueError(f"eval_type must be 'coarse' or 'fine', got {eval_type!r}")
+    with torch.no_grad():
+        refined, confidence, proposals = net.predict_fine(t1, t2, ksize=ksize, ncn_thres=ncn_thres, mutual=mutual)
+    refined, confidence, proposals = _host(refined[0]), _host(confidence[0]), _host(proposals[0])
 
-    pos_ids = np.where(fine_scores > io_thres)[0]
-    if len(pos_ids) > 0:
-        coarse_matches = coarse_matches[pos_ids]
-        matches = fine_matches[pos_ids]
-        scores = fine_scores[pos_ids]
-    else:
-        matches, scores = fine_matches, fine_scores
-    return upscale * matches, scores, upscale * coarse_matches
+    # keep the confident matches; when none clears the threshold every match is returned (reference :97-105)
+    confident = np.flatnonzero(confidence > io_thres)
+    if confident.size:
+        refined, confidence, proposals = refined[confident], confidence[confident], proposals[confident]
+    return to_original * refined, confidence, to_original * proposals
