@@ -87,8 +87,9 @@ __device__ __forceinline__ float sumsq8(const f32x4 &h, const f32x4 &l, float ss
 #define LOADB2(BUF, UNIT_AHEAD)                                                         \
     _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) BUF[q_] = bp[(UNIT_AHEAD) * 128 + q_ * 64];
 // Eight consecutive units, software-pipelined by hand: while unit s runs on the matrix cores, the weight
-// load for unit s+7 (ring of eight register buffers B0..B7) and the LDS reads for unit s+1 (A0_/A1_
-// alternate) are in flight.  The caller pre-loads A0_ with the group's first unit.  (PA0,PA1) / (PB0,PB1)
+// load for unit s+6 (ring of eight register buffers B0..B7) and the LDS reads for unit s+1 (A0_/A1_
+// alternate) are in flight.  The load goes into the buffer that was consumed TWO units ago, never the one the
+// matrix pipe has just read: a VMEM write to a register an in-flight MFMA sources costs ~pass-count wait states.  The caller pre-loads A0_ with the group's first unit.  (PA0,PA1) / (PB0,PB1)
 // are the lane's A addresses of units 0-3 / 4-7 (STEP bytes apart), (NP0,NP1) the first unit of whatever
 // follows.  The sched_barriers pin "loads first, then the MFMAs" and keep later units' loads from being
 // hoisted (which would blow the register budget).
@@ -96,20 +97,20 @@ __device__ __forceinline__ float sumsq8(const f32x4 &h, const f32x4 &l, float ss
     LOADB2(BLOAD, AHEAD) LOADA(ANEXT, (NA0), (NA1), LO) __builtin_amdgcn_sched_barrier(0);                \
     SLAB_MFMA6(C0, C1, ACUR, BCUR) __builtin_amdgcn_sched_barrier(0);
 #define GROUP4H(C0, C1, P0, P1, NP0, NP1, STEP, LO)                                                        \
-    { UNIT_(C0, C1, B3, 3, A1_, (P0) + (STEP), (P1) + (STEP), LO, A0_, B0)                                 \
-      UNIT_(C0, C1, B0, 4, A0_, (P0) + 2 * (STEP), (P1) + 2 * (STEP), LO, A1_, B1)                         \
-      UNIT_(C0, C1, B1, 5, A1_, (P0) + 3 * (STEP), (P1) + 3 * (STEP), LO, A0_, B2)                         \
-      UNIT_(C0, C1, B2, 6, A0_, (NP0), (NP1), LO, A1_, B3)                                                 \
+    { UNIT_(C0, C1, B2, 2, A1_, (P0) + (STEP), (P1) + (STEP), LO, A0_, B0)                                 \
+      UNIT_(C0, C1, B3, 3, A0_, (P0) + 2 * (STEP), (P1) + 2 * (STEP), LO, A1_, B1)                         \
+      UNIT_(C0, C1, B0, 4, A1_, (P0) + 3 * (STEP), (P1) + 3 * (STEP), LO, A0_, B2)                         \
+      UNIT_(C0, C1, B1, 5, A0_, (NP0), (NP1), LO, A1_, B3)                                                 \
       bp += 4 * 128; }
 #define GROUP8H(C0, C1, PA0, PA1, PB0, PB1, NP0, NP1, STEP, LO)                                            \
-    { UNIT_(C0, C1, B7, 7,  A1_, (PA0) + (STEP), (PA1) + (STEP), LO, A0_, B0)                              \
-      UNIT_(C0, C1, B0, 8,  A0_, (PA0) + 2 * (STEP), (PA1) + 2 * (STEP), LO, A1_, B1)                      \
-      UNIT_(C0, C1, B1, 9,  A1_, (PA0) + 3 * (STEP), (PA1) + 3 * (STEP), LO, A0_, B2)                      \
-      UNIT_(C0, C1, B2, 10, A0_, (PB0), (PB1), LO, A1_, B3)                                                \
-      UNIT_(C0, C1, B3, 11, A1_, (PB0) + (STEP), (PB1) + (STEP), LO, A0_, B4)                              \
-      UNIT_(C0, C1, B4, 12, A0_, (PB0) + 2 * (STEP), (PB1) + 2 * (STEP), LO, A1_, B5)                      \
-      UNIT_(C0, C1, B5, 13, A1_, (PB0) + 3 * (STEP), (PB1) + 3 * (STEP), LO, A0_, B6)                      \
-      UNIT_(C0, C1, B6, 14, A0_, (NP0), (NP1), LO, A1_, B7)                                                \
+    { UNIT_(C0, C1, B6, 6,  A1_, (PA0) + (STEP), (PA1) + (STEP), LO, A0_, B0)                              \
+      UNIT_(C0, C1, B7, 7,  A0_, (PA0) + 2 * (STEP), (PA1) + 2 * (STEP), LO, A1_, B1)                      \
+      UNIT_(C0, C1, B0, 8,  A1_, (PA0) + 3 * (STEP), (PA1) + 3 * (STEP), LO, A0_, B2)                      \
+      UNIT_(C0, C1, B1, 9,  A0_, (PB0), (PB1), LO, A1_, B3)                                                \
+      UNIT_(C0, C1, B2, 10, A1_, (PB0) + (STEP), (PB1) + (STEP), LO, A0_, B4)                              \
+      UNIT_(C0, C1, B3, 11, A0_, (PB0) + 2 * (STEP), (PB1) + 2 * (STEP), LO, A1_, B5)                      \
+      UNIT_(C0, C1, B4, 12, A1_, (PB0) + 3 * (STEP), (PB1) + 3 * (STEP), LO, A0_, B6)                      \
+      UNIT_(C0, C1, B5, 13, A0_, (NP0), (NP1), LO, A1_, B7)                                                \
       bp += 8 * 128; }
 
 __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) {
@@ -255,21 +256,21 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
             if (args.n < 0)     // never true: timing experiment without the MFMA loops
 #endif
             {
-            LOADB2(B0, 0) LOADB2(B1, 1) LOADB2(B2, 2)
+            LOADB2(B0, 0) LOADB2(B1, 1)
             {   // level 0 of both images: 4 slabs, already scaled -> straight into the accumulators.  The
                 // stream interleaves the two n-tiles per slab here so that the group has its 8 units.
                 const unsigned char *p0 = smb + A0OFF + l31 * A0ST + half * 16;
                 const unsigned char *p1 = p0 + 32 * A0ST;
                 LOADA(A0_, p0, p1, A0PLANE)
-                UNIT_(acc00, acc10, B3, 3, A1_, p0, p1, A0PLANE, A0_, B0)
-                UNIT_(acc01, acc11, B0, 4, A0_, p0 + 32, p1 + 32, A0PLANE, A1_, B1)
-                UNIT_(acc00, acc10, B1, 5, A1_, p0 + 32, p1 + 32, A0PLANE, A0_, B2)
-                UNIT_(acc01, acc11, B2, 6, A0_, p0 + 64, p1 + 64, A0PLANE, A1_, B3)
+                UNIT_(acc00, acc10, B2, 2, A1_, p0, p1, A0PLANE, A0_, B0)
+                UNIT_(acc01, acc11, B3, 3, A0_, p0 + 32, p1 + 32, A0PLANE, A1_, B1)
+                UNIT_(acc00, acc10, B0, 4, A1_, p0 + 32, p1 + 32, A0PLANE, A0_, B2)
+                UNIT_(acc01, acc11, B1, 5, A0_, p0 + 64, p1 + 64, A0PLANE, A1_, B3)
                 bp += 4 * 128;
-                UNIT_(acc00, acc10, B3, 3, A1_, p0 + 64, p1 + 64, A0PLANE, A0_, B0)
-                UNIT_(acc01, acc11, B0, 4, A0_, p0 + 96, p1 + 96, A0PLANE, A1_, B1)
-                UNIT_(acc00, acc10, B1, 5, A1_, p0 + 96, p1 + 96, A0PLANE, A0_, B2)
-                UNIT_(acc01, acc11, B2, 6, A0_, p0, p1, A0PLANE, A1_, B3)
+                UNIT_(acc00, acc10, B2, 2, A1_, p0 + 64, p1 + 64, A0PLANE, A0_, B0)
+                UNIT_(acc01, acc11, B3, 3, A0_, p0 + 96, p1 + 96, A0PLANE, A1_, B1)
+                UNIT_(acc00, acc10, B0, 4, A1_, p0 + 96, p1 + 96, A0PLANE, A0_, B2)
+                UNIT_(acc01, acc11, B1, 5, A0_, p0, p1, A0PLANE, A1_, B3)
                 bp += 4 * 128;
             }
 #pragma unroll 1
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
         {
             const f32x4 *bp = (const f32x4 *)R.ws2 + (size_t)wave * (S2_UNITS + SPF) * 128 + lane;
             f32x4 B0[2], B1[2], B2[2], B3[2], B4[2], B5[2], B6[2], B7[2], A0_[4], A1_[4];
-            LOADB2(B0, 0) LOADB2(B1, 1) LOADB2(B2, 2) LOADB2(B3, 3) LOADB2(B4, 4) LOADB2(B5, 5) LOADB2(B6, 6)
+            LOADB2(B0, 0) LOADB2(B1, 1) LOADB2(B2, 2) LOADB2(B3, 3) LOADB2(B4, 4) LOADB2(B5, 5)
 #ifdef P2P_SPLIT_SKIP_CONV
             if (args.n < 0)
 #endif
