@@ -393,3 +393,31 @@ def test_images_of_different_sizes(dev, ops, weights):
     # clamping uses each image's own size: x1 <= 96, y1 <= 64, x2 <= 64, y2 <= 96
     hi = torch.tensor([96.0, 64.0, 64.0, 96.0])
     assert (out["matches1"].cpu() <= hi).all() and (out["matches1"].cpu() >= 0).all()
+
+
+def test_stream_equals_per_pair_calls(dev, tmp_path):
+    """estimate_matches_stream (threaded loading, batched backbone, shared fine launch) returns what
+    estimate_matches returns pair by pair.  The batched backbone may differ from the un-batched one in the last
+    bits (MIOpen algorithm choice), so rows are matched by their coarse match and compared with a tolerance."""
+    from PIL import Image
+    from patch2pix_amd.utils.eval import model_helper
+    from patch2pix_amd.utils.eval.stream import estimate_matches_stream
+    net = _model(dev)
+    pairs = []
+    for i, (h, w) in enumerate([(240, 320), (240, 320), (240, 320), (192, 256), (192, 256), (240, 320)]):
+        a, b = synthetic.make_image_pair(300 + i, h, w)
+        pa, pb = tmp_path / f"{i}a.jpg", tmp_path / f"{i}b.jpg"
+        Image.fromarray(a).save(pa, quality=95)
+        Image.fromarray(b).save(pb, quality=95)
+        pairs.append((str(pa), str(pb)))
+    streamed = list(estimate_matches_stream(net, pairs, ksize=2, io_thres=0.25, batch=3, workers=3))
+    assert len(streamed) == len(pairs)
+    for (m, s, c), (pa, pb) in zip(streamed, pairs):
+        rm, rs, rc = model_helper.estimate_matches(net, pa, pb, ksize=2, io_thres=0.25)
+        assert m.dtype == np.float64 and s.dtype == np.float32 and c.dtype == np.float64
+        ref = {tuple(np.round(r, 6)): i for i, r in enumerate(rc)}
+        hits = [(i, ref[tuple(np.round(r, 6))]) for i, r in enumerate(c) if tuple(np.round(r, 6)) in ref]
+        assert len(hits) >= 0.9 * max(len(rc), 1), (len(hits), len(rc))
+        if hits:
+            gi = np.array([h[0] for h in hits]); ri = np.array([h[1] for h in hits])
+            assert np.median(np.abs(m[gi] - rm[ri]).max(axis=1)) < 0.02

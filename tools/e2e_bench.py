@@ -22,6 +22,20 @@ with tempfile.TemporaryDirectory() as td:
             m, s, c = model_helper.estimate_matches(net, pa, pb, ksize=2, io_thres=0.25); n += 1
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"end-to-end estimate_matches: {n/dt:.1f} pairs/s ({dt/n*1e3:.1f} ms/pair), {m.shape[0]} matches in the last pair")
+    # streaming form: threaded loading, batched backbone, shared fine launch
+    from patch2pix_amd.utils.eval.stream import estimate_matches_stream
+    for ext, q in (("jpg", {"quality": 95}), ("png", {})):
+        files = []
+        for i in range(8):
+            a, b = synthetic.make_image_pair(200 + i, 480, 640)
+            pa, pb = os.path.join(td, f"s{i}a.{ext}"), os.path.join(td, f"s{i}b.{ext}")
+            Image.fromarray(a).save(pa, **q); Image.fromarray(b).save(pb, **q); files.append((pa, pb))
+        work = files * 8
+        list(estimate_matches_stream(net, files, batch=8, workers=16))
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        nres = sum(1 for _ in estimate_matches_stream(net, work, batch=8, workers=16))
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f"end-to-end estimate_matches_stream ({ext}): {nres/dt:.1f} pairs/s ({dt/nres*1e3:.1f} ms/pair)")
     # backbone only
     im = torch.randn(1, 3, 480, 640, device="cuda")
     with torch.no_grad():
