@@ -113,6 +113,12 @@ __device__ __forceinline__ float sumsq8(const f32x4 &h, const f32x4 &l, float ss
       UNIT_(C0, C1, B5, 13, A0_, (NP0), (NP1), LO, A1_, B7)                                                \
       bp += 8 * 128; }
 
+#ifdef P2P_SPLIT_TIMING
+#define STAMP(i) stamps[i] = __builtin_amdgcn_s_memtime();
+#else
+#define STAMP(i)
+#endif
+
 __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
     const int tid = threadIdx.x;
@@ -148,6 +154,10 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
 #define X0(img_) ((img_) ? xb : xa)
 #define Y0(img_) ((img_) ? yb : ya)
         __syncthreads();
+#ifdef P2P_SPLIT_TIMING
+        unsigned long long stamps[12];
+#endif
+        STAMP(0)
         // Opaque copy of the thread id for the staging phases: their index arithmetic depends only on the
         // thread id, and without this the compiler hoists all of it out of the level loop and spills it
         // (scratch must stay at zero, see build.py).
@@ -166,43 +176,79 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
 #ifdef P2P_SPLIT_SKIP_GATHER
         if (args.n < 0)
 #endif
-        for (int img = 0; img < 2; ++img) {
-            const int Hh = I.H[img], Ww = I.W[img];
-            {   // level 0: raw fp32 [3][16x16]
-                const int r0 = clampi(Y0(img), 0, Hh - 1), c0 = clampi(X0(img), 0, Ww - 1);
-                const float *src = I.pyr[img][0];
-                for (int e = tidv; e < 3 * 256; e += NT) {
-                    const int c = e >> 8, rem = e & 255, r = rem >> 4, cc = rem & 15;
-                    raw0[img * 768 + e] = src[((size_t)c * Hh + min(r0 + r, Hh - 1)) * Ww + min(c0 + cc, Ww - 1)];
+        {
+            // two passes so that all ~40 scattered 4-byte loads of a thread are in flight together:
+            // first every address and load (both images, levels 0-3), then split + store
+            float g0[2][2], g1[2][11], g2[2][4], g3[2][3];
+#pragma unroll
+            for (int img = 0; img < 2; ++img) {
+                const int Hh = I.H[img], Ww = I.W[img];
+                {
+                    const int r0 = clampi(Y0(img), 0, Hh - 1), c0 = clampi(X0(img), 0, Ww - 1);
+                    const float *src = I.pyr[img][0];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int e = tidv + k * NT;
+                        const int c = e >> 8, rem = e & 255, r = rem >> 4, cc = rem & 15;
+                        g0[img][k] = (e < 768) ? src[((size_t)c * Hh + min(r0 + r, Hh - 1)) * Ww + min(c0 + cc, Ww - 1)] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int j = 1; j < 4; ++j) {
+                    const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
+                    const int Cc = (j == 3) ? 128 : 64;
+                    const int nk = (j == 1) ? 11 : (j == 2) ? 4 : 3;
+                    const int Hj = Hh >> j, Wj = Ww >> j;
+                    const int r0 = clampi(Y0(img) >> j, 0, Hj - 1);
+                    const int c0 = clampi(X0(img) >> j, 0, Wj - 1);
+                    const float *src = I.pyr[img][j];
+#pragma unroll
+                    for (int k = 0; k < nk; ++k) {
+                        const int e = tidv + k * NT;
+                        const int c = e / (Rr * Rr);
+                        const int rem = e - c * (Rr * Rr);
+                        const int r = rem / Rr;
+                        const int cc = rem - r * Rr;
+                        const float v = (e < Cc * Rr * Rr)
+                                            ? src[((size_t)c * Hj + min(r0 + r, Hj - 1)) * Wj + min(c0 + cc, Wj - 1)] : 0.f;
+                        if (j == 1) g1[img][k] = v; else if (j == 2) g2[img][k] = v; else g3[img][k] = v;
+                    }
                 }
             }
-            unsigned char *tb = smb + img * IMGB;
 #pragma unroll
-            for (int j = 1; j < 4; ++j) {
-                const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
-                const int Cc = (j == 3) ? 128 : 64;
-                const int off = (j == 1) ? OFF1 : (j == 2) ? OFF2 : OFF3;
-                const int st = (j == 3) ? ST3 : ST1;
-                const int Hj = Hh >> j, Wj = Ww >> j;
-                const int r0 = clampi(Y0(img) >> j, 0, Hj - 1);
-                const int c0 = clampi(X0(img) >> j, 0, Wj - 1);
-                const float *src = I.pyr[img][j];
-#pragma unroll 8
-                for (int e = tidv; e < Cc * Rr * Rr; e += NT) {
-                    const int c = e / (Rr * Rr);
-                    const int rem = e - c * (Rr * Rr);
-                    const int r = rem / Rr;
-                    const int cc = rem - r * Rr;
-                    const float v = src[((size_t)c * Hj + min(r0 + r, Hj - 1)) * Wj + min(c0 + cc, Wj - 1)];
-                    const unsigned short hi = f2bf(v);
-                    const unsigned short lo = f2bf(v - bf2f(hi));
-                    unsigned char *dst = tb + off + rem * st + c * 2;
-                    *(unsigned short *)dst = hi;
-                    *(unsigned short *)(dst + PLANE) = lo;
+            for (int img = 0; img < 2; ++img) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int e = tidv + k * NT;
+                    if (e < 768) raw0[img * 768 + e] = g0[img][k];
+                }
+                unsigned char *tb = smb + img * IMGB;
+#pragma unroll
+                for (int j = 1; j < 4; ++j) {
+                    const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
+                    const int Cc = (j == 3) ? 128 : 64;
+                    const int nk = (j == 1) ? 11 : (j == 2) ? 4 : 3;
+                    const int off = (j == 1) ? OFF1 : (j == 2) ? OFF2 : OFF3;
+                    const int st = (j == 3) ? ST3 : ST1;
+#pragma unroll
+                    for (int k = 0; k < nk; ++k) {
+                        const int e = tidv + k * NT;
+                        if (e < Cc * Rr * Rr) {
+                            const int c = e / (Rr * Rr);
+                            const int rem = e - c * (Rr * Rr);
+                            const float v = (j == 1) ? g1[img][k] : (j == 2) ? g2[img][k] : g3[img][k];
+                            const unsigned short hi = f2bf(v);
+                            const unsigned short lo = f2bf(v - bf2f(hi));
+                            unsigned char *dst = tb + off + rem * st + c * 2;
+                            *(unsigned short *)dst = hi;
+                            *(unsigned short *)(dst + PLANE) = lo;
+                        }
+                    }
                 }
             }
         }
         __syncthreads();
+        STAMP(1)
 
         // ------------------------------------------------------------ per-pixel L2 scale (patch2pix.py:173-174)
         {
@@ -226,6 +272,7 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
             scale[tid] = 1.0f / sqrtf(ss + 1e-6f);
         }
         __syncthreads();
+        STAMP(2)
 
         // ------------------------------------------------------------ level-0 im2col block, pre-scaled and split
         for (int e = tidv; e < 64 * 64; e += NT) {
@@ -246,6 +293,7 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
         }
         __syncthreads();
 
+        STAMP(3)
         // ------------------------------------------------------------ conv1: 3x3, stride 2, pad 1
         f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
         {
@@ -324,6 +372,7 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
             }
             }
         }
+        STAMP(4)
         __syncthreads();   // all waves are done reading the conv1 operands
 
         // BN1 -> split -> H[pixel][channel] (bf16 hi / lo planes), plus the all-zero padding row
@@ -357,6 +406,7 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
         }
         __syncthreads();
 
+        STAMP(5)
         // ------------------------------------------------------------ conv2: 3x3, stride 1, pad 1
         acc00 = (f32x16){0}; acc01 = (f32x16){0}; acc10 = (f32x16){0}; acc11 = (f32x16){0};
         {
@@ -392,6 +442,7 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
             }
         }
 
+        STAMP(6)
         // BN2 -> ReLU -> max over the 8x8 outputs
         {
 #pragma unroll
@@ -412,10 +463,19 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
         }
         __syncthreads();
 
+        STAMP(7)
 #ifdef P2P_SPLIT_SKIP_FC
         if (args.n < 0)
 #endif
         fc_tail_parse(R, I, args, lvl, prop, tid, V, F1, F2, misc);
+        STAMP(8)
+#ifdef P2P_SPLIT_TIMING
+        // raw[0] doubles as the stamp buffer in timing builds: workgroups < 64 record [prop][wave][8] phase lengths
+        if (args.raw[0] && prop < 64 && lane == 0 && lvl == 0) {
+            float *dbg = args.raw[0] + 5 * args.n + (prop * 8 + wave) * 8;
+            for (int i = 0; i < 8; ++i) dbg[i] = (float)(stamps[i + 1] - stamps[i]);
+        }
+#endif
     }
 }
 
