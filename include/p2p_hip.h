@@ -84,7 +84,7 @@ int p2p_regressor_get_mode(const p2p_regressor *reg);
 
 /* ---- coarse stage ---------------------------------------------------------------------------- */
 
-/* Workspace (bytes) p2p_coarse_forward needs for these sizes. */
+/* Workspace (bytes) p2p_coarse_forward needs for these sizes (per pair). */
 size_t p2p_coarse_workspace_bytes(int channels, int hA, int wA, int hB, int wB, int ksize);
 
 /* Patch2Pix.forward_coarse_match -- reference networks/patch2pix.py:120-136:
@@ -100,6 +100,15 @@ int p2p_coarse_forward(const float *featA, const float *featB, int channels, int
                        int ksize, const p2p_ncn *ncn, float *corr4d_out, uint8_t *delta_out,
                        void *workspace, size_t workspace_bytes, p2p_stream_t stream);
 
+/* The same for the batch axis of the reference's tensors (feat1/feat2 are [B,C,h,w] in
+ * networks/patch2pix.py:120-136): `batch` equally sized pairs, contiguous along the leading axis in all four
+ * arrays, one launch per kernel for the whole batch.  The workspace must hold at least one pair
+ * (p2p_coarse_workspace_bytes); with batch x that size all pairs are processed together, with less they are
+ * processed in as many groups as fit.                                                             */
+int p2p_coarse_forward_batch(const float *featA, const float *featB, int batch, int channels, int hA, int wA, int hB,
+                             int wB, int ksize, const p2p_ncn *ncn, float *corr4d_out, uint8_t *delta_out,
+                             void *workspace, size_t workspace_bytes, p2p_stream_t stream);
+
 /* Expand the packed relocalisation byte into the reference's four int64 tensors
  * (max_i, max_j, max_k, max_l of modules.py:24-28); `out` holds 4 consecutive planes of n int64. */
 int p2p_delta_unpack(const uint8_t *delta, size_t n, int ksize, int64_t *out, p2p_stream_t stream);
@@ -112,6 +121,11 @@ int p2p_delta_unpack(const uint8_t *delta, size_t n, int ksize, int64_t *out, p2
  * corr4d dims are the pooled ones; delta may be NULL (ksize 1).                                  */
 int p2p_coarse_matches(const float *corr4d, const uint8_t *delta, int hA, int wA, int hB, int wB, int ksize,
                        int upsample, int center, int64_t *matches_out, float *scores_out, p2p_stream_t stream);
+
+/* Batch form: corr4d [B, ...], delta [B, ...], matches_out [B, nB + nA, 4], scores_out [B, nB + nA]. */
+int p2p_coarse_matches_batch(const float *corr4d, const uint8_t *delta, int batch, int hA, int wA, int hB, int wB,
+                             int ksize, int upsample, int center, int64_t *matches_out, float *scores_out,
+                             p2p_stream_t stream);
 
 /* ---- fine stage ------------------------------------------------------------------------------ */
 

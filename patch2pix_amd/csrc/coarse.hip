@@ -13,8 +13,15 @@
 //                         volume is never permuted)
 // The full-resolution correlation (92 MB at 480x640, 1.5 GB at 960x1280) is never written: the
 // pooling runs on the MFMA accumulators of the correlation GEMM.
+//
+// Batches: the reference's tensors carry a batch axis ([B,C,h,w] features of B equally sized pairs).  Every
+// kernel takes the pair from blockIdx.z and a per-pair stride for each of its pointers, so a batch is
+// ONE launch per kernel (B x the work-groups: the 30x40x30x40 volume of a single 480x640 pair does not
+// fill 256 CUs in the consensus layers).
 #include "p2p_common.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace p2p {
@@ -34,7 +41,9 @@ constexpr int KEY_NEG_INF = (int)0xff800000 ^ 0x7fffffff;
 // ------------------------------------------------------------------------------------------------
 constexpr int PREP_P = 16;    // positions per work-group (300 groups at 60x80: fills the chip)
 __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ F, float *__restrict__ Fn, int C, int h,
-                                                   int w, int k) {
+                                                   int w, int k, size_t sF, size_t sFn) {
+    F += blockIdx.z * sF;
+    Fn += blockIdx.z * sFn;
     __shared__ float tile[256 * (PREP_P + 1)];   // [C <= 256][17]
     __shared__ float part[16][PREP_P];
     __shared__ float inv[PREP_P];
@@ -88,7 +97,12 @@ constexpr int CLD = 36;      // LDS row stride (floats): 16-B aligned, conflict-
 template <int KS>
 __global__ __launch_bounds__(256) void corr_pool_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                         int nA, int nB, int C, float *__restrict__ P,
-                                                        uint8_t *__restrict__ delta) {
+                                                        uint8_t *__restrict__ delta, size_t sAB, size_t sP,
+                                                        size_t sDelta) {
+    A += blockIdx.z * sAB;
+    B += blockIdx.z * sAB;
+    P += blockIdx.z * sP;
+    if (delta) delta += blockIdx.z * sDelta;
     __shared__ __attribute__((aligned(16))) float As[CT * CLD];
     __shared__ __attribute__((aligned(16))) float Bs[CT * CLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -179,13 +193,16 @@ __global__ __launch_bounds__(256) void corr_pool_kernel(const float *__restrict_
 // ------------------------------------------------------------------------------------------------
 // 3. row / column maxima of an [nA][nB] matrix (the two torch.max of ncn/model.py:165-166)
 // ------------------------------------------------------------------------------------------------
-__global__ void fill_keys_kernel(int *p, int n) {
+__global__ void fill_keys_kernel(int *p, int n, size_t sKeys) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = KEY_NEG_INF;
+    if (i < n) p[blockIdx.z * sKeys + i] = KEY_NEG_INF;
 }
 
 // column maxima: a thread owns one column over a 64-row chunk; chunks meet in an (order independent) atomicMax
-__global__ __launch_bounds__(256) void colmax_kernel(const float *__restrict__ X, int nA, int nB, int *ckey) {
+__global__ __launch_bounds__(256) void colmax_kernel(const float *__restrict__ X, int nA, int nB, int *ckey, size_t sX,
+                                                     size_t sKeys) {
+    X += blockIdx.z * sX;
+    ckey += blockIdx.z * sKeys;
     const int col = blockIdx.x * 256 + threadIdx.x;
     if (col >= nB) return;
     const int r0 = blockIdx.y * 64, r1 = min(r0 + 64, nA);
@@ -196,7 +213,10 @@ __global__ __launch_bounds__(256) void colmax_kernel(const float *__restrict__ X
 }
 
 // row maxima: one wave per row
-__global__ __launch_bounds__(256) void rowmax_kernel(const float *__restrict__ X, int nA, int nB, int *rkey) {
+__global__ __launch_bounds__(256) void rowmax_kernel(const float *__restrict__ X, int nA, int nB, int *rkey, size_t sX,
+                                                     size_t sKeys) {
+    X += blockIdx.z * sX;
+    rkey += blockIdx.z * sKeys;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= nA) return;
     const float *x = X + (size_t)row * nB;
@@ -214,79 +234,87 @@ __device__ __forceinline__ float mm_value(float x, float max_over_b, float max_o
     return x * (xa * xb);
 }
 
-__global__ __launch_bounds__(256) void mm_apply_kernel(const float *__restrict__ X, int nA, int nB,
-                                                       const int *__restrict__ rkey, const int *__restrict__ ckey,
-                                                       float *__restrict__ out) {
+// (in place when out == X)
+__global__ __launch_bounds__(256) void mm_apply_kernel(const float *X, int nA, int nB, const int *__restrict__ rkey,
+                                                       const int *__restrict__ ckey, float *out, size_t sX, size_t sKeys,
+                                                       size_t sOut, float *__restrict__ zero) {
+    X += blockIdx.z * sX;
+    rkey += blockIdx.z * sKeys;
+    ckey += blockIdx.z * sKeys;
+    out += blockIdx.z * sOut;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)nA * nB) return;
     const int r = (int)(i / nB), c = (int)(i - (size_t)r * nB);
     out[i] = mm_value(X[i], key2f(rkey[r]), key2f(ckey[c]));
+    if (zero) zero[blockIdx.z * sX + i] = 0.f;      // same index space: clears the accumulation target of consensus layer 2
 }
 
 // ------------------------------------------------------------------------------------------------
 // 4. neighbourhood consensus (ncn/model.py:145-155; conv4d.py:12-74), 1 -> 16 -> 1 channels, both
-//    symmetric branches.  Work-group tile: 1 x 4 x 8 x 8 outputs with a one-cell halo in LDS.
+//    symmetric branches.
 // ------------------------------------------------------------------------------------------------
-constexpr int TB_ = 4, TC_ = 8, TD_ = 8;
-constexpr int HB_ = TB_ + 2, HC_ = TC_ + 2, HD_ = TD_ + 2;
-constexpr int HALO = 3 * HB_ * HC_ * HD_;      // 1800 cells
-
 struct Vol { int d0, d1, d2, d3; };
 
-__device__ __forceinline__ void tile_origin(const Vol &v, int &a, int &b0, int &c0, int &d0) {
-    const int nd = (v.d3 + TD_ - 1) / TD_, nc = (v.d2 + TC_ - 1) / TC_, nb = (v.d1 + TB_ - 1) / TB_;
-    int t = blockIdx.x;
-    d0 = (t % nd) * TD_; t /= nd;
-    c0 = (t % nc) * TC_; t /= nc;
-    b0 = (t % nb) * TB_; t /= nb;
-    a = t;
-}
+// layer 1: X (mutual matching already applied) -> H1[32][nA][nB], bias + ReLU.
+// Work-group: one a, L1_TB rows b, L1_Q consecutive B cells q = c*d3 + d.  A wave therefore stores 256
+// contiguous bytes per hidden channel (the 184 MB of H1 per 480x640 pair is the kernel's real cost), for any
+// d3.  The input halo is staged as whole (c) rows: [3 a][L1_TB+2 b][nrc c][d3+2] floats.
+constexpr int L1_TB = 4, L1_Q = 64;
+static int l1_rows(int d3) { return (L1_Q - 2) / d3 + 2 + 2; }      // c-rows L1_Q consecutive cells can touch, + halo
 
-// layer 1: X (mutual matching applied on load) -> H1[32][nA][nB], bias + ReLU
-__global__ __launch_bounds__(256) void nc_layer1_kernel(const float *__restrict__ X, Vol v,
-                                                        const int *__restrict__ rkey, const int *__restrict__ ckey,
-                                                        const float *__restrict__ w1cat, const float *__restrict__ b1cat,
-                                                        float *__restrict__ H1) {
-    __shared__ float tile[HALO];
-    int a, b0, c0, d0;
-    tile_origin(v, a, b0, c0, d0);
-    const int tid = threadIdx.x;
+__global__ __launch_bounds__(256) void nc_layer1_kernel(const float *__restrict__ X, Vol v, const float *__restrict__ w1cat,
+                                                        const float *__restrict__ b1cat, float *__restrict__ H1, size_t sWs) {
+    extern __shared__ float tile1[];
+    X += blockIdx.z * sWs;
+    H1 += blockIdx.z * sWs;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nB = v.d2 * v.d3;
     const size_t nAB = (size_t)v.d0 * v.d1 * nB;
-    for (int e = tid; e < HALO; e += 256) {
-        int t = e;
-        const int dd = t % HD_; t /= HD_;
-        const int dc = t % HC_; t /= HC_;
-        const int db = t % HB_; t /= HB_;
-        const int ia = a + t - 1, ib = b0 + db - 1, ic = c0 + dc - 1, id = d0 + dd - 1;
-        float val = 0.f;
-        if (ia >= 0 && ia < v.d0 && ib >= 0 && ib < v.d1 && ic >= 0 && ic < v.d2 && id >= 0 && id < v.d3) {
-            const int ra = ia * v.d1 + ib, cb = ic * v.d3 + id;
-            val = mm_value(X[(size_t)ra * nB + cb], key2f(rkey[ra]), key2f(ckey[cb]));
-        }
-        tile[e] = val;
+    const int nq = (nB + L1_Q - 1) / L1_Q, nbt = (v.d1 + L1_TB - 1) / L1_TB;
+    int g = blockIdx.x;
+    const int q0 = (g % nq) * L1_Q; g /= nq;
+    const int b0 = (g % nbt) * L1_TB; g /= nbt;
+    const int a = g;
+    const int c_lo = q0 / v.d3 - 1, c_hi = min(q0 + L1_Q - 1, nB - 1) / v.d3 + 1;
+    const int nrc = c_hi - c_lo + 1, W = v.d3 + 2;
+    constexpr int HB = L1_TB + 2;
+    // stage: one wave instruction per (a, b, c) row, lane = column (d = column - 1)
+    for (int r = wave; r < 3 * HB * nrc; r += 4) {
+        const int rc = r % nrc, db = (r / nrc) % HB, da = r / (nrc * HB);
+        const int ia = a + da - 1, ib = b0 + db - 1, ic = c_lo + rc;
+        const bool rok = ia >= 0 && ia < v.d0 && ib >= 0 && ib < v.d1 && ic >= 0 && ic < v.d2;
+        const float *src = X + ((size_t)(ia * v.d1 + ib) * v.d2 + ic) * v.d3 - 1;
+        for (int col = lane; col < W; col += 64)
+            tile1[r * W + col] = (rok && col >= 1 && col <= v.d3) ? src[col] : 0.f;
     }
     __syncthreads();
-    const int tb = tid >> 6, tc = (tid >> 3) & 7, td = tid & 7;
+    const int tb = wave, cb = q0 + lane;
+    const int c = cb / v.d3, d = cb - c * v.d3;
+    const int ib = b0 + tb;
+    const bool active = cb < nB && ib < v.d1;
     float acc[32];
 #pragma unroll
     for (int o = 0; o < 32; ++o) acc[o] = 0.f;
-    for (int da = 0; da < 3; ++da)
-        for (int db = 0; db < 3; ++db) {
-            const float *tp = tile + ((da * HB_ + tb + db) * HC_ + tc) * HD_ + td;
-            const float *wp = w1cat + (da * 3 + db) * 9 * 32;
+    if (active) {
+        const float *base = tile1 + (tb * nrc + (c - c_lo - 1)) * W + d;
+#ifdef P2P_NC1_SKIP_COMPUTE
+        for (int da = 0; da < (v.d0 < 0 ? 3 : 0); ++da)
+#else
+        for (int da = 0; da < 3; ++da)
+#endif
+            for (int db = 0; db < 3; ++db) {
+                const float *tp = base + (da * HB + db) * nrc * W;
+                const float *wp = w1cat + (da * 3 + db) * 9 * 32;
 #pragma unroll
-            for (int dc = 0; dc < 3; ++dc)
+                for (int dc = 0; dc < 3; ++dc)
 #pragma unroll
-                for (int dd = 0; dd < 3; ++dd) {
-                    const float x = tp[dc * HD_ + dd];
+                    for (int dd = 0; dd < 3; ++dd) {
+                        const float x = tp[dc * W + dd];
 #pragma unroll
-                    for (int o = 0; o < 32; ++o) acc[o] = fmaf(x, wp[(dc * 3 + dd) * 32 + o], acc[o]);
-                }
-        }
-    const int ib = b0 + tb, ic = c0 + tc, id = d0 + td;
-    if (ib < v.d1 && ic < v.d2 && id < v.d3) {
-        const size_t pos = (size_t)(a * v.d1 + ib) * nB + ic * v.d3 + id;
+                        for (int o = 0; o < 32; ++o) acc[o] = fmaf(x, wp[(dc * 3 + dd) * 32 + o], acc[o]);
+                    }
+            }
+        const size_t pos = (size_t)(a * v.d1 + ib) * nB + cb;
 #pragma unroll
         for (int o = 0; o < 32; ++o) H1[o * nAB + pos] = fmaxf(acc[o] + b1cat[o], 0.f);
     }
@@ -294,166 +322,236 @@ __global__ __launch_bounds__(256) void nc_layer1_kernel(const float *__restrict_
 
 // layer 2: Y = relu(b2 + sum_{c<16} W2*H1[c]) + relu(b2 + sum_{c<16} W2^T*H1[16+c])
 //
-// Work-group tile: 1 x tb x tc x (8*tdr) outputs; a thread owns a run of 8 consecutive outputs along
-// the last axis, so every 10-float LDS row read feeds 24 FMAs.  One hidden channel at a time is
-// staged (3 x (tb+2) x (tc+2) rows with halo, row stride 8*tdr+4 floats so that ds_read_b128 stays
-// 16-B aligned); at ~44 KB per work-group three of them share a CU and overlap each other's loads.
-struct NcTile { int tb, tc, tdr, rs; };
-constexpr int NC_MAX_ITERS = 12;      // FULLROW staging: wave instructions per channel stage (3*(tb+2)*(tc+2) rows / (4*rpi))
+// Work-group tile: ta x tb x tc x (8*tdr) outputs.  A thread owns a run of 8 consecutive outputs along the last
+// axis at one (b, c) and MARCHES along the first axis: the a-slices of the hidden volume are staged one at a
+// time (one channel per stage, (tb+2) x (tc+2) rows with halo, double buffered), and every 10-float LDS row
+// read feeds the three output slices it contributes to (taps da = 0,1,2 -> outputs a+1, a, a-1): 72 FMAs per
+// row read instead of 24, which is what takes the kernel off the LDS pipe.  Row stride 8*tdr+12 floats keeps
+// ds_read_b128 16-B aligned and bank-conflict free for the rows-fastest thread order.
+// The two symmetric branches only meet in the final sum of their ReLUs, so blockIdx.y = branch: each group
+// convolves 16 channels and adds relu(b2 + sum) into Y with a hardware float atomic.  Y is zero beforehand and
+// gets exactly two addends per cell, so the result does not depend on which branch arrives first.
+struct NcTile { int tb, tc, tdr, rs, ta, nthreads; };
+constexpr int NC_MAX_ITERS = 6;      // FULLROW staging: 16-byte loads per thread and stage
+constexpr int NC_MAX_ROWS = 24;      // general staging: rows per wave and stage
+
+// The nine staged rows (db, dc) around this thread's run, each applied to the three output slices it feeds.
+// ALL = every slice is wanted (interior of the march): straight-line code, the 81 scalar weight loads of the
+// channel are free to run ahead of their use.  Otherwise the unwanted slices are skipped with uniform branches.
+template <bool ALL>
+__device__ __forceinline__ void nc2_rows(const float *cb, const float *__restrict__ wch, int hc, int rs, bool useP, bool useC,
+                                         bool useN, float (&aP)[8], float (&aC)[8], float (&aN)[8]) {
+#pragma unroll
+    for (int db = 0; db < 3; ++db)
+#pragma unroll
+        for (int dc = 0; dc < 3; ++dc) {
+            const float *p = cb + (db * hc + dc) * rs;
+            const f32x4 x0 = *(const f32x4 *)p, x1 = *(const f32x4 *)(p + 4);
+            const float x8 = p[8], x9 = p[9];
+            const float x[10] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3], x8, x9};
+            float w[9];                                  // [da][dd]
+#pragma unroll
+            for (int q = 0; q < 9; ++q) w[q] = wch[(db * 3 + dc) * 9 + q];
+            if (ALL || useN) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) aN[i] = fmaf(x[i + 2], w[2], fmaf(x[i + 1], w[1], fmaf(x[i], w[0], aN[i])));
+            }
+            if (ALL || useC) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) aC[i] = fmaf(x[i + 2], w[5], fmaf(x[i + 1], w[4], fmaf(x[i], w[3], aC[i])));
+            }
+            if (ALL || useP) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) aP[i] = fmaf(x[i + 2], w[8], fmaf(x[i + 1], w[7], fmaf(x[i], w[6], aP[i])));
+            }
+        }
+}
 
 // FULLROW: the tile spans the whole last axis (one d-tile, d3 % 4 == 0): rows are staged with 16-byte
-// loads, several rows per wave instruction, all of a stage's loads in flight at once.
+// loads, several rows per wave instruction.  Otherwise one wave instruction stages one row (+ halo columns).
 template <bool FULLROW>
 __global__ __launch_bounds__(256) void nc_layer2_kernel(const float *__restrict__ H1, Vol v, NcTile t,
-                                                        const float *__restrict__ w2cat, float b2,
-                                                        float *__restrict__ Y) {
-    extern __shared__ __attribute__((aligned(16))) float tile2[];      // [3][tb+2][tc+2][rs]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                                        const float *__restrict__ w2m, float b2,
+                                                        float *__restrict__ Y, size_t sWs) {
+    extern __shared__ __attribute__((aligned(16))) float tile2[];      // [2][(tb+2)*(tc+2)][rs], then int rowoff[]
+    H1 += blockIdx.z * sWs + (size_t)blockIdx.y * 16 * ((size_t)v.d0 * v.d1 * v.d2 * v.d3);      // this branch's 16 channels
+    Y += blockIdx.z * sWs;
+    w2m += blockIdx.y * 16 * 81;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int td = 8 * t.tdr;
     const int nd = (v.d3 + td - 1) / td, nc = (v.d2 + t.tc - 1) / t.tc, nb = (v.d1 + t.tb - 1) / t.tb;
     int g = blockIdx.x;
     const int d0 = (g % nd) * td; g /= nd;
     const int c0 = (g % nc) * t.tc; g /= nc;
     const int b0 = (g % nb) * t.tb; g /= nb;
-    const int a = g;
-    const int nB = v.d2 * v.d3;
-    const size_t nAB = (size_t)v.d0 * v.d1 * nB;
-    const int hb = t.tb + 2, hc = t.tc + 2, ncol = td + 2;
-    const int nrows = 3 * hb * hc;
+    const int a0 = g * t.ta, a1 = min(a0 + t.ta, v.d0);       // this group's output slices [a0, a1)
+    const size_t slice = (size_t)v.d1 * v.d2 * v.d3;
+    const size_t nAB = (size_t)v.d0 * slice;
+    const int hc = t.tc + 2, nrows = (t.tb + 2) * hc, ncol = td + 2;
+    float *buf0 = tile2, *buf1 = tile2 + nrows * t.rs;
+    int *rowoff = (int *)(tile2 + 2 * nrows * t.rs);
     // this thread's run of 8 outputs
-    const int rc = tid % t.tc, rr = (tid / t.tc) % t.tdr, rb = tid / (t.tdr * t.tc);   // rows fastest: fewer LDS bank conflicts
+    const int rc = tid % t.tc, rr = (tid / t.tc) % t.tdr, rb = tid / (t.tdr * t.tc);   // rows fastest: no LDS bank conflicts
     const bool active = rb < t.tb;
-    float out[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) out[i] = 0.f;
+    const int myoff = (rb * hc + rc) * t.rs + 8 * rr;
 
-    // source offset of every staged row (identical for all 32 channels): computed once
-    int *rowoff = (int *)(tile2 + nrows * t.rs);
-    for (int r = tid; r < nrows; r += 256) {
-        const int dc = r % hc, db = (r / hc) % hb, da = r / (hc * hb);
-        const int ia = a + da - 1, ib = b0 + db - 1, ic = c0 + dc - 1;
-        const bool rok = ia >= 0 && ia < v.d0 && ib >= 0 && ib < v.d1 && ic >= 0 && ic < v.d2;
-        rowoff[r] = rok ? ((ia * v.d1 + ib) * v.d2 + ic) * v.d3 : -1;
+    // source offset of every staged row inside an a-slice (identical for all slices and channels)
+    for (int r = tid; r < nrows; r += blockDim.x) {
+        const int dc = r % hc, db = r / hc;
+        const int ib = b0 + db - 1, ic = c0 + dc - 1;
+        rowoff[r] = (ib >= 0 && ib < v.d1 && ic >= 0 && ic < v.d2) ? (ib * v.d2 + ic) * v.d3 : -1;
+        if (FULLROW) {      // the two halo columns are outside the volume: zero once, never overwritten
+            buf0[r * t.rs] = 0.f; buf0[r * t.rs + v.d3 + 1] = 0.f;
+            buf1[r * t.rs] = 0.f; buf1[r * t.rs + v.d3 + 1] = 0.f;
+        }
     }
-    const int colid = d0 + lane - 1;
-    const bool colok = lane < ncol && colid >= 0 && colid < v.d3;
-    // FULLROW staging geometry: lpr lanes x float4 per row, rpi rows per wave instruction
-    const int lpr = v.d3 >> 2, rpi = 64 / max(lpr, 1);
-    const int myr = lane / max(lpr, 1), myq = lane - myr * lpr;
+    // staging geometry
+    const int lpr = max(v.d3 >> 2, 1), rpi = 64 / lpr;            // FULLROW: lanes per row, rows per wave instruction
+    const int myr = lane / lpr, myq = lane - myr * lpr;
     const bool lane_ok = myr < rpi;
-    const int niter = (nrows + 4 * rpi - 1) / (4 * rpi);
-    if (FULLROW) {      // the two halo columns are outside the volume: zero once, never overwritten
-        for (int r = tid; r < nrows; r += 256) { tile2[r * t.rs] = 0.f; tile2[r * t.rs + v.d3 + 1] = 0.f; }
-    }
-    const int slab_c = t.rs, slab_b = hc * t.rs, slab_a = hb * hc * t.rs;
-    const float *mybase = tile2 + (rb * hc + rc) * t.rs + 8 * rr;
+    const int niter = (nrows + nwaves * rpi - 1) / (nwaves * rpi);
+    const int colid = d0 + lane - 1;                              // general: lane = column
+    const bool colok = lane < ncol && colid >= 0 && colid < v.d3;
 
-    // FULLROW: the rows of hidden channel ch+1 are fetched into registers (16-byte loads, all in flight) while
-    // channel ch is convolved out of LDS, and written to LDS after the barrier that ends that compute.
-    f32x4 vals[NC_MAX_ITERS];
-    auto fetch = [&](int chn) {
-        const float *src = H1 + (size_t)chn * nAB;
+    // One stage = one a-slice of one hidden channel: fetched into registers while the previous stage is being
+    // convolved out of LDS, then written to the other LDS buffer.
+    f32x4 vq[NC_MAX_ITERS];
+    float vs[NC_MAX_ROWS];
+    auto fetch = [&](int s, int ch) {
+        const float *src = H1 + (size_t)ch * nAB + (size_t)s * slice;
+        if (FULLROW) {
 #pragma unroll
-        for (int i = 0; i < NC_MAX_ITERS; ++i) {
-            const int r = (i * 4 + wave) * rpi + myr;
-            const int off = (i < niter && lane_ok && r < nrows) ? rowoff[r] : -1;
-            vals[i] = (off >= 0) ? *(const f32x4 *)(src + off + 4 * myq) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < NC_MAX_ITERS; ++i) {
+                const int r = (i * nwaves + wave) * rpi + myr;
+                const int off = (i < niter && lane_ok && r < nrows) ? rowoff[r] : -1;
+                vq[i] = (off >= 0) ? *(const f32x4 *)(src + off + 4 * myq) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NC_MAX_ROWS; ++u) {
+                const int r = wave + nwaves * u;
+                const int off = (r < nrows) ? rowoff[r] : -1;
+                vs[u] = (off >= 0 && colok) ? src[off + colid] : 0.f;
+            }
         }
     };
-    if (FULLROW) {
-        __syncthreads();        // rowoff / halo zeros are ready
-        fetch(0);
-    }
-    for (int branch = 0; branch < 2; ++branch) {
-        float acc[8];
+    auto commit = [&](float *buf) {
+        if (FULLROW) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-        for (int ch = 0; ch < 16; ++ch) {
-            const float *src = H1 + (size_t)(branch * 16 + ch) * nAB;
-            __syncthreads();
-            if (FULLROW) {
-#pragma unroll
-                for (int i = 0; i < NC_MAX_ITERS; ++i) {
-                    const int r = (i * 4 + wave) * rpi + myr;
-                    if (i < niter && lane_ok && r < nrows) {
-                        float *dst = tile2 + r * t.rs + 1 + 4 * myq;
-                        dst[0] = vals[i][0]; dst[1] = vals[i][1]; dst[2] = vals[i][2]; dst[3] = vals[i][3];
-                    }
-                }
-            } else {
-            // stage one channel: each wave copies whole rows (coalesced along the last axis), eight
-            // rows in flight per wave so that the loads overlap
-            for (int r0 = wave; r0 < nrows; r0 += 32) {
-                float v8[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int r = r0 + 4 * u;
-                    const int off = (r < nrows) ? rowoff[r] : -1;
-                    v8[u] = (off >= 0 && colok) ? src[off + colid] : 0.f;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int r = r0 + 4 * u;
-                    if (r < nrows && lane < ncol) tile2[r * t.rs + lane] = v8[u];
+            for (int i = 0; i < NC_MAX_ITERS; ++i) {
+                const int r = (i * nwaves + wave) * rpi + myr;
+                if (i < niter && lane_ok && r < nrows) {
+                    float *dst = buf + r * t.rs + 1 + 4 * myq;
+                    dst[0] = vq[i][0]; dst[1] = vq[i][1]; dst[2] = vq[i][2]; dst[3] = vq[i][3];
                 }
             }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NC_MAX_ROWS; ++u) {
+                const int r = wave + nwaves * u;
+                if (r < nrows && lane < ncol) buf[r * t.rs + lane] = vs[u];
             }
-            __syncthreads();
-            if (FULLROW && branch * 16 + ch + 1 < 32) fetch(branch * 16 + ch + 1);
-            if (active) {
-                const float *wch = w2cat + (branch * 16 + ch) * 81;
-                for (int da = 0; da < 3; ++da)
-                    for (int db = 0; db < 3; ++db) {
+        }
+    };
+
+    // partial sums of the three output slices a staged slice s contributes to: P -> out[s-1], C -> out[s],
+    // N -> out[s+1]; [run position]
+    float accP[8], accC[8], accN[8];
 #pragma unroll
-                        for (int dc = 0; dc < 3; ++dc) {
-                            const float *p = mybase + da * slab_a + db * slab_b + dc * slab_c;
-                            const f32x4 x0 = *(const f32x4 *)p, x1 = *(const f32x4 *)(p + 4);
-                            const float x8 = p[8], x9 = p[9];
-                            const float x[10] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3], x8, x9};
-                            const float *w = wch + (da * 3 + db) * 9 + dc * 3;
-                            const float w0 = w[0], w1 = w[1], w2 = w[2];
+    for (int i = 0; i < 8; ++i) accP[i] = accC[i] = accN[i] = 0.f;
+
+    const int s_first = max(a0 - 1, 0), s_last = min(a1, v.d0 - 1);    // slices outside the volume are all zero
+    __syncthreads();        // rowoff / halo zeros are ready
+    fetch(s_first, 0);
+    commit(buf0);
+    __syncthreads();
+    int cur = 0;
+    for (int s = a0 - 1; s <= a1; ++s) {
+        if (s >= s_first && s <= s_last) {
+            const bool useP = s - 1 >= a0, useC = s >= a0 && s < a1, useN = s + 1 < a1;
+#pragma unroll 1
+            for (int ch = 0; ch < 16; ++ch) {
+                const bool more = ch < 15 || s < s_last;
+#ifdef P2P_NC2_SKIP_STAGE
+                if (more && v.d0 < 0) {
+#else
+                if (more) {
+#endif
+                    if (ch < 15) fetch(s, ch + 1);
+                    else fetch(s + 1, 0);
+                }
+#ifdef P2P_NC2_SKIP_COMPUTE
+                if (active && v.d0 < 0) {
+#else
+                if (active) {
+#endif
+                    const float *cb = (cur ? buf1 : buf0) + myoff;
+                    const float *wch = w2m + ch * 81;
+                    if (useP && useC && useN) nc2_rows<true>(cb, wch, hc, t.rs, true, true, true, accP, accC, accN);
+                    else nc2_rows<false>(cb, wch, hc, t.rs, useP, useC, useN, accP, accC, accN);
+                }
+                if (more) commit(cur ? buf0 : buf1);
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+        // every slice that feeds out[s-1] has been seen
+        const int a = s - 1;
+        if (active && a >= a0) {
+            const int ib = b0 + rb, ic = c0 + rc;
+            if (ib < v.d1 && ic < v.d2) {
+                float *dst = Y + (((size_t)a * v.d1 + ib) * v.d2 + ic) * v.d3;
 #pragma unroll
-                            for (int i = 0; i < 8; ++i)
-                                acc[i] = fmaf(x[i + 2], w2, fmaf(x[i + 1], w1, fmaf(x[i], w0, acc[i])));
-                        }
-                    }
+                for (int i = 0; i < 8; ++i) {
+                    const int id = d0 + 8 * rr + i;
+                    if (id < v.d3) unsafeAtomicAdd(dst + id, fmaxf(accP[i] + b2, 0.f));
+                }
             }
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) out[i] += fmaxf(acc[i] + b2, 0.f);
-    }
-    if (active) {
-        const int ib = b0 + rb, ic = c0 + rc;
-        if (ib < v.d1 && ic < v.d2) {
-            float *dst = Y + ((size_t)(a * v.d1 + ib) * v.d2 + ic) * v.d3;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int id = d0 + 8 * rr + i;
-                if (id < v.d3) dst[id] = out[i];
-            }
-        }
+        for (int i = 0; i < 8; ++i) { accP[i] = accC[i]; accC[i] = accN[i]; accN[i] = 0.f; }
     }
 }
 
-// tile shape with the least padding for this volume (<= 256 runs, <= 52 KB of LDS so 3 groups fit a CU)
-static NcTile pick_nc_tile(const Vol &v) {
-    NcTile best{4, 8, 4, 44};
-    double best_eff = -1;
+static bool nc_fullrow(const Vol &v, const NcTile &t) {
+    const int lpr = v.d3 / 4, nrows = (t.tb + 2) * (t.tc + 2), nwaves = t.nthreads / 64;
+    return (v.d3 % 4 == 0) && (8 * t.tdr >= v.d3) && lpr >= 1 && lpr <= 64 &&
+           ceil_div(nrows, nwaves * (64 / lpr)) <= NC_MAX_ITERS;
+}
+static size_t nc_lds_bytes(const NcTile &t) {
+    const size_t nrows = (size_t)(t.tb + 2) * (t.tc + 2);
+    return (2 * nrows * t.rs + nrows) * 4;
+}
+
+// Tile shape for this volume and batch.  Model: every configuration does the same useful work, split into
+// `waves` wavefronts that each cost ta (FMA) + 0.85 (ta+2) (LDS reads, staging and barriers of the ta+2 slices
+// they march through); the chip runs 1024 of them at a time and hides latency poorly below two per SIMD.
+static NcTile pick_nc_tile(const Vol &v, int batch) {
+    NcTile best{4, 6, 5, 52, 3, 128};
+    if (const char *e = getenv("P2P_NC2_TILE")) {      // experiments: "tb,tc,tdr,ta,nthreads"
+        NcTile t{};
+        if (sscanf(e, "%d,%d,%d,%d,%d", &t.tb, &t.tc, &t.tdr, &t.ta, &t.nthreads) == 5) { t.rs = 8 * t.tdr + 12; return t; }
+    }
+    double best_cost = 1e300;
     const int tbs[] = {2, 3, 4, 5, 6, 8}, tcs[] = {4, 5, 6, 8, 10, 12, 15, 16}, tdrs[] = {2, 3, 4, 5, 6, 7};   // 8*tdr+2 columns must fit one wave
-    for (int tdr : tdrs)
-        for (int tb : tbs)
-            for (int tc : tcs) {
-                if (tb * tc * tdr > 256) continue;
-                const int rs = 8 * tdr + 12;   // 52 words for 40-wide rows: best of the multiples of 4 for ds_read_b128 (bank model)
-                const size_t lds = (size_t)3 * (tb + 2) * (tc + 2) * (rs + 1) * 4;
-                if (lds > 54000) continue;                 // three groups per CU (160 KiB)
-                const double groups = (double)v.d0 * ceil_div(v.d1, tb) * ceil_div(v.d2, tc) * ceil_div(v.d3, 8 * tdr);
-                const double useful = (double)v.d0 * v.d1 * v.d2 * v.d3;
-                // padding efficiency x halo efficiency (staged cells per useful output)
-                const double eff = useful / (groups * 256 * 8) *
-                                   ((double)tb * tc * 8 * tdr / ((tb + 2) * (tc + 2) * (8 * tdr + 2)));
-                if (eff > best_eff) { best_eff = eff; best = NcTile{tb, tc, tdr, rs}; }
-            }
+    const int tas[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 15, 16, 20, 30};
+    const int nts[] = {128, 256};
+    for (int nthreads : nts)
+        for (int tdr : tdrs)
+            for (int tb : tbs)
+                for (int tc : tcs) {
+                    if (tb * tc * tdr > nthreads) continue;
+                    NcTile t{tb, tc, tdr, 8 * tdr + 12, 1, nthreads};   // 52 words for 40-wide rows: conflict-free ds_read_b128 (bank model)
+                    if (nc_lds_bytes(t) > 40000) continue;             // four groups per CU (160 KiB)
+                    if (ceil_div((tb + 2) * (tc + 2), nthreads / 64) > NC_MAX_ROWS) continue;
+                    for (int ta : tas) {
+                        if (ta > v.d0 && ta != 1) continue;
+                        const double groups = (double)ceil_div(v.d0, ta) * ceil_div(v.d1, tb) * ceil_div(v.d2, tc) * ceil_div(v.d3, 8 * tdr);
+                        const double wps = groups * batch * 2 * (nthreads / 64) / 1024.0;      // waves per SIMD (two branches)
+                        const double cost = (ta + 0.85 * (ta + 2)) * (wps > 1 ? wps : 1.0) * (wps < 2 ? 1.25 : 1.0);
+                        if (cost < best_cost) { best_cost = cost; best = t; best.ta = ta; }
+                    }
+                }
     return best;
 }
 
@@ -466,7 +564,15 @@ struct MatchArgs {
     int hA, wA, hB, wB, ksize, upsample, center;
     long long *matches;
     float *scores;
+    size_t sX, sM;      // per-pair strides: cells of the volume, rows of the match list
 };
+__device__ __forceinline__ MatchArgs match_args_of_pair(MatchArgs m, size_t z) {
+    m.X += z * m.sX;
+    if (m.delta) m.delta += z * m.sX;
+    m.matches += z * m.sM * 4;
+    m.scores += z * m.sM;
+    return m;
+}
 
 __device__ __forceinline__ void emit_match(const MatchArgs &m, int out_row, int ra, int cb, float sum_exp) {
     int ia = ra / m.wA, ja = ra - ia * m.wA, ib = cb / m.wB, jb = cb - ib * m.wB;
@@ -487,7 +593,8 @@ __device__ __forceinline__ void emit_match(const MatchArgs &m, int out_row, int 
 }
 
 // direction B->A: one block per 8 columns, 32 interleaved row slices
-__global__ __launch_bounds__(256) void match_cols_kernel(MatchArgs m) {
+__global__ __launch_bounds__(256) void match_cols_kernel(MatchArgs m_) {
+    const MatchArgs m = match_args_of_pair(m_, blockIdx.z);
     __shared__ float smax[32][8];
     __shared__ int sarg[32][8];
     __shared__ float ssum[32][8];
@@ -526,7 +633,8 @@ __global__ __launch_bounds__(256) void match_cols_kernel(MatchArgs m) {
 }
 
 // direction A->B: one wave per row
-__global__ __launch_bounds__(256) void match_rows_kernel(MatchArgs m) {
+__global__ __launch_bounds__(256) void match_rows_kernel(MatchArgs m_) {
+    const MatchArgs m = match_args_of_pair(m_, blockIdx.z);
     const int nA = m.hA * m.wA, nB = m.hB * m.wB;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -589,7 +697,7 @@ extern "C" int p2p_ncn_create(const float *w1, const float *b1, const float *w2,
     P2P_REQUIRE(w1 && b1 && w2 && b2 && out, P2P_EINVAL, "p2p_ncn_create: null argument");
     // stored layout (conv4d.py:119-120): w1s[da][o][ci=0][db][dc][dd], w2s[da][o=0][ci][db][dc][dd]
     std::vector<float> h(81 * 32 + 32 + 32 * 81, 0.f);
-    float *w1cat = h.data(), *b1cat = w1cat + 81 * 32, *w2cat = b1cat + 32;
+    float *w1cat = h.data(), *b1cat = w1cat + 81 * 32, *w2m = b1cat + 32;
     auto W1 = [&](int o, int da, int db, int dc, int dd) { return w1[(((da * 16 + o) * 3 + db) * 3 + dc) * 3 + dd]; };
     auto W2 = [&](int c, int da, int db, int dc, int dd) { return w2[(((da * 16 + c) * 3 + db) * 3 + dc) * 3 + dd]; };
     for (int da = 0; da < 3; ++da)
@@ -600,8 +708,10 @@ extern "C" int p2p_ncn_create(const float *w1, const float *b1, const float *w2,
                     for (int o = 0; o < 16; ++o) {
                         w1cat[tap * 32 + o] = W1(o, da, db, dc, dd);
                         w1cat[tap * 32 + 16 + o] = W1(o, dc, dd, da, db);      // transposed branch
-                        w2cat[o * 81 + tap] = W2(o, da, db, dc, dd);
-                        w2cat[(16 + o) * 81 + tap] = W2(o, dc, dd, da, db);
+                        // layer 2 is consumed row by row of the staged slice: [channel][db][dc][da][dd]
+                        const int m = ((db * 3 + dc) * 3 + da) * 3 + dd;
+                        w2m[o * 81 + m] = W2(o, da, db, dc, dd);
+                        w2m[(16 + o) * 81 + m] = W2(o, dc, dd, da, db);
                     }
                 }
     for (int o = 0; o < 16; ++o) b1cat[o] = b1cat[16 + o] = b1[o];
@@ -614,7 +724,7 @@ extern "C" int p2p_ncn_create(const float *w1, const float *b1, const float *w2,
         return P2P_EHIP;
     }
     p2p_ncn *n = new p2p_ncn();
-    n->dev = dev; n->w1cat = dev; n->b1cat = dev + 81 * 32; n->w2cat = dev + 81 * 32 + 32; n->b2 = b2[0];
+    n->dev = dev; n->w1cat = dev; n->b1cat = dev + 81 * 32; n->w2m = dev + 81 * 32 + 32; n->b2 = b2[0];
     *out = n;
     return P2P_OK;
 }
@@ -630,57 +740,82 @@ extern "C" size_t p2p_coarse_workspace_bytes(int channels, int hA, int wA, int h
     return coarse_ws(channels, hA, wA, hB, wB, ksize).total;
 }
 
-extern "C" int p2p_coarse_forward(const float *featA, const float *featB, int C, int hA, int wA, int hB, int wB,
-                                  int ksize, const p2p_ncn *ncn, float *corr4d_out, uint8_t *delta_out,
-                                  void *workspace, size_t workspace_bytes, p2p_stream_t stream_) {
+extern "C" int p2p_coarse_forward_batch(const float *featA, const float *featB, int batch, int C, int hA, int wA, int hB,
+                                        int wB, int ksize, const p2p_ncn *ncn, float *corr4d_out, uint8_t *delta_out,
+                                        void *workspace, size_t workspace_bytes, p2p_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     P2P_REQUIRE(featA && featB && ncn && corr4d_out && workspace, P2P_EINVAL, "p2p_coarse_forward: null argument");
+    P2P_REQUIRE(batch >= 1 && batch <= 65535, P2P_EINVAL, "p2p_coarse_forward: batch %d out of range", batch);
     P2P_REQUIRE(ksize == 1 || ksize == 2, P2P_EUNSUPPORTED, "p2p_coarse_forward: ksize %d not supported (1 or 2)", ksize);
     P2P_REQUIRE(C > 0 && C % 32 == 0 && C <= 256, P2P_EUNSUPPORTED, "p2p_coarse_forward: channels %d (multiple of 32, <= 256)", C);
     P2P_REQUIRE(hA > 0 && wA > 0 && hB > 0 && wB > 0 && hA % ksize == 0 && wA % ksize == 0 && hB % ksize == 0 &&
                     wB % ksize == 0, P2P_EINVAL, "p2p_coarse_forward: feature map sizes must be positive multiples of ksize");
     const CoarseWs ws = coarse_ws(C, hA, wA, hB, wB, ksize);
-    P2P_REQUIRE(workspace_bytes >= ws.total, P2P_ENOMEM, "p2p_coarse_forward: workspace %zu < %zu bytes", workspace_bytes, ws.total);
-    char *base = (char *)workspace;
-    float *fnA = (float *)(base + ws.fnA), *fnB = (float *)(base + ws.fnB);
-    float *P = (float *)(base + ws.P), *Y = (float *)(base + ws.Y), *H1 = (float *)(base + ws.H1);
+    P2P_REQUIRE(workspace_bytes >= ws.total, P2P_ENOMEM, "p2p_coarse_forward: workspace %zu < %zu bytes (one pair)", workspace_bytes,
+                ws.total);
     const int nA = hA * wA, nB = hB * wB, kk = ksize * ksize;
     const int nAc = nA / kk, nBc = nB / kk;
-    int *rkey1 = (int *)(base + ws.keys), *ckey1 = rkey1 + nAc, *rkey2 = ckey1 + nBc, *ckey2 = rkey2 + nAc;
-
-    hipLaunchKernelGGL(prep_kernel, dim3(ceil_div(nA, PREP_P)), dim3(256), 0, stream, featA, fnA, C, hA, wA, ksize);
-    hipLaunchKernelGGL(prep_kernel, dim3(ceil_div(nB, PREP_P)), dim3(256), 0, stream, featB, fnB, C, hB, wB, ksize);
-    const dim3 cgrid(ceil_div(nB, CT), ceil_div(nA, CT));
-    if (ksize == 1)
-        hipLaunchKernelGGL(corr_pool_kernel<1>, cgrid, dim3(256), 0, stream, fnA, fnB, nA, nB, C, P, (uint8_t *)nullptr);
-    else
-        hipLaunchKernelGGL(corr_pool_kernel<2>, cgrid, dim3(256), 0, stream, fnA, fnB, nA, nB, C, P, delta_out);
-
-    const int nkeys = 2 * (nAc + nBc);
-    hipLaunchKernelGGL(fill_keys_kernel, dim3(ceil_div(nkeys, 256)), dim3(256), 0, stream, rkey1, nkeys);
-    const dim3 mgrid(ceil_div(nBc, 256), ceil_div(nAc, 64));
-    hipLaunchKernelGGL(colmax_kernel, mgrid, dim3(256), 0, stream, P, nAc, nBc, ckey1);
-    hipLaunchKernelGGL(rowmax_kernel, dim3(ceil_div(nAc, 4)), dim3(256), 0, stream, P, nAc, nBc, rkey1);
-
-    Vol v{hA / ksize, wA / ksize, hB / ksize, wB / ksize};
-    const int ntiles = v.d0 * ceil_div(v.d1, TB_) * ceil_div(v.d2, TC_) * ceil_div(v.d3, TD_);
-    hipLaunchKernelGGL(nc_layer1_kernel, dim3(ntiles), dim3(256), 0, stream, P, v, rkey1, ckey1, ncn->w1cat, ncn->b1cat, H1);
-    const NcTile nt = pick_nc_tile(v);
-    const int ntiles2 = v.d0 * ceil_div(v.d1, nt.tb) * ceil_div(v.d2, nt.tc) * ceil_div(v.d3, 8 * nt.tdr);
-    const size_t lds2 = (size_t)3 * (nt.tb + 2) * (nt.tc + 2) * (nt.rs + 1) * 4;
-    const int lpr = v.d3 / 4, rows2 = 3 * (nt.tb + 2) * (nt.tc + 2);
-    const bool fullrow = (v.d3 % 4 == 0) && (8 * nt.tdr >= v.d3) && lpr >= 1 && lpr <= 64 &&
-                         ceil_div(rows2, 4 * (64 / lpr)) <= NC_MAX_ITERS;
-    if (fullrow)
-        hipLaunchKernelGGL(nc_layer2_kernel<true>, dim3(ntiles2), dim3(256), lds2, stream, H1, v, nt, ncn->w2cat, ncn->b2, Y);
-    else
-        hipLaunchKernelGGL(nc_layer2_kernel<false>, dim3(ntiles2), dim3(256), lds2, stream, H1, v, nt, ncn->w2cat, ncn->b2, Y);
-    hipLaunchKernelGGL(colmax_kernel, mgrid, dim3(256), 0, stream, Y, nAc, nBc, ckey2);
-    hipLaunchKernelGGL(rowmax_kernel, dim3(ceil_div(nAc, 4)), dim3(256), 0, stream, Y, nAc, nBc, rkey2);
     const size_t nel = (size_t)nAc * nBc;
-    hipLaunchKernelGGL(mm_apply_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, stream, Y, nAc, nBc, rkey2, ckey2,
-                       corr4d_out);
+    const size_t sWs = ws.total / 4;        // every workspace buffer of pair z sits z * ws.total bytes further on
+    const int per_launch = (int)std::min<size_t>(batch, workspace_bytes / ws.total);   // pairs the workspace holds at once
+    const Vol v{hA / ksize, wA / ksize, hB / ksize, wB / ksize};
+
+    for (int z0 = 0; z0 < batch; z0 += per_launch) {
+        const unsigned nz = (unsigned)std::min(per_launch, batch - z0);
+        const float *fA = featA + (size_t)z0 * C * nA, *fB = featB + (size_t)z0 * C * nB;
+        float *out = corr4d_out + (size_t)z0 * nel;
+        uint8_t *dout = delta_out ? delta_out + (size_t)z0 * nel : nullptr;
+        char *base = (char *)workspace;
+        float *fnA = (float *)(base + ws.fnA), *fnB = (float *)(base + ws.fnB);
+        float *P = (float *)(base + ws.P), *Y = (float *)(base + ws.Y), *H1 = (float *)(base + ws.H1);
+        int *rkey1 = (int *)(base + ws.keys), *ckey1 = rkey1 + nAc, *rkey2 = ckey1 + nBc, *ckey2 = rkey2 + nAc;
+
+        hipLaunchKernelGGL(prep_kernel, dim3(ceil_div(nA, PREP_P), 1, nz), dim3(256), 0, stream, fA, fnA, C, hA, wA, ksize,
+                           (size_t)C * nA, sWs);
+        hipLaunchKernelGGL(prep_kernel, dim3(ceil_div(nB, PREP_P), 1, nz), dim3(256), 0, stream, fB, fnB, C, hB, wB, ksize,
+                           (size_t)C * nB, sWs);
+        const dim3 cgrid(ceil_div(nB, CT), ceil_div(nA, CT), nz);
+        if (ksize == 1)
+            hipLaunchKernelGGL(corr_pool_kernel<1>, cgrid, dim3(256), 0, stream, fnA, fnB, nA, nB, C, P, (uint8_t *)nullptr, sWs,
+                               sWs, (size_t)0);
+        else
+            hipLaunchKernelGGL(corr_pool_kernel<2>, cgrid, dim3(256), 0, stream, fnA, fnB, nA, nB, C, P, dout, sWs, sWs, nel);
+
+        const int nkeys = 2 * (nAc + nBc);
+        hipLaunchKernelGGL(fill_keys_kernel, dim3(ceil_div(nkeys, 256), 1, nz), dim3(256), 0, stream, rkey1, nkeys, sWs);
+        const dim3 mgrid(ceil_div(nBc, 256), ceil_div(nAc, 64), nz);
+        hipLaunchKernelGGL(colmax_kernel, mgrid, dim3(256), 0, stream, P, nAc, nBc, ckey1, sWs, sWs);
+        hipLaunchKernelGGL(rowmax_kernel, dim3(ceil_div(nAc, 4), 1, nz), dim3(256), 0, stream, P, nAc, nBc, rkey1, sWs, sWs);
+
+        // first mutual matching, in place on the pooled volume (also clears Y for layer 2's atomic adds)
+        hipLaunchKernelGGL(mm_apply_kernel, dim3((unsigned)((nel + 255) / 256), 1, nz), dim3(256), 0, stream, P, nAc, nBc, rkey1,
+                           ckey1, P, sWs, sWs, sWs, Y);
+        const int ntiles = v.d0 * ceil_div(v.d1, L1_TB) * ceil_div(nBc, L1_Q);
+        const size_t lds1 = (size_t)3 * (L1_TB + 2) * l1_rows(v.d3) * (v.d3 + 2) * 4;
+        P2P_REQUIRE(lds1 <= 64 * 1024, P2P_EUNSUPPORTED, "p2p_coarse_forward: pooled width %d too large for the consensus tile", v.d3);
+        hipLaunchKernelGGL(nc_layer1_kernel, dim3(ntiles, 1, nz), dim3(256), lds1, stream, P, v, ncn->w1cat, ncn->b1cat, H1, sWs);
+        const NcTile nt = pick_nc_tile(v, (int)nz);
+        const int ntiles2 = ceil_div(v.d0, nt.ta) * ceil_div(v.d1, nt.tb) * ceil_div(v.d2, nt.tc) * ceil_div(v.d3, 8 * nt.tdr);
+        const size_t lds2 = nc_lds_bytes(nt);
+        if (nc_fullrow(v, nt))
+            hipLaunchKernelGGL(nc_layer2_kernel<true>, dim3(ntiles2, 2, nz), dim3(nt.nthreads), lds2, stream, H1, v, nt, ncn->w2m,
+                               ncn->b2, Y, sWs);
+        else
+            hipLaunchKernelGGL(nc_layer2_kernel<false>, dim3(ntiles2, 2, nz), dim3(nt.nthreads), lds2, stream, H1, v, nt, ncn->w2m,
+                               ncn->b2, Y, sWs);
+        hipLaunchKernelGGL(colmax_kernel, mgrid, dim3(256), 0, stream, Y, nAc, nBc, ckey2, sWs, sWs);
+        hipLaunchKernelGGL(rowmax_kernel, dim3(ceil_div(nAc, 4), 1, nz), dim3(256), 0, stream, Y, nAc, nBc, rkey2, sWs, sWs);
+        hipLaunchKernelGGL(mm_apply_kernel, dim3((unsigned)((nel + 255) / 256), 1, nz), dim3(256), 0, stream, Y, nAc, nBc, rkey2,
+                           ckey2, out, sWs, sWs, nel, (float *)nullptr);
+    }
     return check_launch("coarse_forward kernels");
+}
+
+extern "C" int p2p_coarse_forward(const float *featA, const float *featB, int C, int hA, int wA, int hB, int wB,
+                                  int ksize, const p2p_ncn *ncn, float *corr4d_out, uint8_t *delta_out,
+                                  void *workspace, size_t workspace_bytes, p2p_stream_t stream) {
+    return p2p_coarse_forward_batch(featA, featB, 1, C, hA, wA, hB, wB, ksize, ncn, corr4d_out, delta_out, workspace,
+                                    workspace_bytes, stream);
 }
 
 extern "C" int p2p_delta_unpack(const uint8_t *delta, size_t n, int ksize, int64_t *out, p2p_stream_t stream) {
@@ -691,14 +826,22 @@ extern "C" int p2p_delta_unpack(const uint8_t *delta, size_t n, int ksize, int64
     return check_launch("delta_unpack_kernel");
 }
 
-extern "C" int p2p_coarse_matches(const float *corr4d, const uint8_t *delta, int hA, int wA, int hB, int wB, int ksize,
-                                  int upsample, int center, int64_t *matches_out, float *scores_out, p2p_stream_t stream) {
+extern "C" int p2p_coarse_matches_batch(const float *corr4d, const uint8_t *delta, int batch, int hA, int wA, int hB, int wB,
+                                        int ksize, int upsample, int center, int64_t *matches_out, float *scores_out,
+                                        p2p_stream_t stream) {
     P2P_REQUIRE(corr4d && matches_out && scores_out, P2P_EINVAL, "p2p_coarse_matches: null argument");
+    P2P_REQUIRE(batch >= 1 && batch <= 65535, P2P_EINVAL, "p2p_coarse_matches: batch %d out of range", batch);
     P2P_REQUIRE(hA > 0 && wA > 0 && hB > 0 && wB > 0 && ksize >= 1, P2P_EINVAL, "p2p_coarse_matches: bad sizes");
     P2P_REQUIRE(ksize == 1 || delta, P2P_EINVAL, "p2p_coarse_matches: delta required when ksize > 1");
-    MatchArgs m{corr4d, delta, hA, wA, hB, wB, ksize, upsample, center, (long long *)matches_out, scores_out};
     const int nA = hA * wA, nB = hB * wB;
-    hipLaunchKernelGGL(match_cols_kernel, dim3(ceil_div(nB, 8)), dim3(256), 0, (hipStream_t)stream, m);
-    hipLaunchKernelGGL(match_rows_kernel, dim3(ceil_div(nA, 4)), dim3(256), 0, (hipStream_t)stream, m);
+    MatchArgs m{corr4d, delta, hA, wA, hB, wB, ksize, upsample, center, (long long *)matches_out, scores_out,
+                (size_t)nA * nB, (size_t)nA + nB};
+    hipLaunchKernelGGL(match_cols_kernel, dim3(ceil_div(nB, 8), 1, batch), dim3(256), 0, (hipStream_t)stream, m);
+    hipLaunchKernelGGL(match_rows_kernel, dim3(ceil_div(nA, 4), 1, batch), dim3(256), 0, (hipStream_t)stream, m);
     return check_launch("match kernels");
+}
+
+extern "C" int p2p_coarse_matches(const float *corr4d, const uint8_t *delta, int hA, int wA, int hB, int wB, int ksize,
+                                  int upsample, int center, int64_t *matches_out, float *scores_out, p2p_stream_t stream) {
+    return p2p_coarse_matches_batch(corr4d, delta, 1, hA, wA, hB, wB, ksize, upsample, center, matches_out, scores_out, stream);
 }

@@ -49,7 +49,7 @@ struct p2p_ncn {
     float *dev;        // one device allocation holding everything below
     float *w1cat;      // [81][32]  layer-1 taps x (16 direct-branch + 16 transposed-branch) channels
     float *b1cat;      // [32]
-    float *w2cat;      // [32][81]  layer-2: channels 0-15 direct branch, 16-31 transposed branch
+    float *w2m;        // [32][db][dc][da][dd]  layer-2: channels 0-15 direct branch, 16-31 transposed branch
     float b2;          // scalar bias of layer 2 (same for both branches)
 };
 

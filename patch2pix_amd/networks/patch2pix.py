@@ -59,14 +59,14 @@ class Delta4d:
     (networks/modules.py:24-34), kept packed (one byte per cell) until somebody indexes it."""
 
     def __init__(self, packed, ksize):
-        self.packed = packed            # list over batch of uint8 [h1,w1,h2,w2]
+        self.packed = packed            # uint8 [B,h1,w1,h2,w2]
         self.ksize = ksize
         self._planes = None
 
     def _materialise(self):
         if self._planes is None:
-            per_item = [ops.delta_unpack(p, self.ksize) for p in self.packed]
-            self._planes = tuple(torch.stack([it[i] for it in per_item]).unsqueeze(1) for i in range(4))
+            planes = ops.delta_unpack(self.packed, self.ksize)          # four int64 [B,h1,w1,h2,w2]
+            self._planes = tuple(p.unsqueeze(1) for p in planes)
         return self._planes
 
     def __iter__(self):
@@ -175,10 +175,9 @@ class Patch2Pix(nn.Module):
         shape = (b, 1, h1 // k, w1 // k, h2 // k, w2 // k)
         corr4d = torch.empty(shape, dtype=torch.float32, device=feat1.device)
         packed = torch.empty(shape, dtype=torch.uint8, device=feat1.device) if ksize > 1 else None
-        for i in range(b):
-            ops.coarse_forward(feat1[i], feat2[i], ksize, ncn, out_corr=corr4d[i, 0],
-                               out_delta=packed[i, 0] if packed is not None else None)
-        delta4d = Delta4d([packed[i, 0] for i in range(b)], ksize) if ksize > 1 else None
+        ops.coarse_forward_batch(feat1, feat2, ksize, ncn, out_corr=corr4d[:, 0],
+                                 out_delta=packed[:, 0] if packed is not None else None)
+        delta4d = Delta4d(packed[:, 0], ksize) if ksize > 1 else None
         return corr4d, delta4d
 
     def forward(self, im1, im2, ksize=1, return_feats=False):
@@ -201,14 +200,10 @@ class Patch2Pix(nn.Module):
         if delta4d is not None and not isinstance(delta4d, Delta4d):
             di, dj, dk, dl = delta4d            # reference-format int64 planes -> packed byte
             s = ((di * ksize + dj) * ksize + dk) * ksize + dl
-            delta4d = Delta4d([p[0].to(torch.uint8).contiguous() for p in s], ksize)
+            delta4d = Delta4d(s[:, 0].to(torch.uint8).contiguous(), ksize)
         nb, _, h1, w1, h2, w2 = corr4d.shape
-        n = h1 * w1 + h2 * w2
-        matches_ = torch.empty((nb, n, 4), dtype=torch.int64, device=corr4d.device)
-        score_ = torch.empty((nb, n), dtype=torch.float32, device=corr4d.device)
-        for b in range(nb):
-            ops.coarse_matches(corr4d[b, 0], delta4d.packed[b] if delta4d is not None else None,
-                               ksize, upsample, center, out_matches=matches_[b], out_scores=score_[b])
+        matches_, score_ = ops.coarse_matches_batch(corr4d[:, 0], delta4d.packed if delta4d is not None else None,
+                                                    ksize, upsample, center)
         if sort:
             order = torch.sort(-score_)[1]
             score_ = torch.gather(score_, 1, order)

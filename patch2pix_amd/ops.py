@@ -1,6 +1,7 @@
 """Torch-tensor front end of the C ABI: owns nothing but the two kinds of weight handle.
 Every function launches asynchronously on torch's current HIP stream of the tensors' device."""
 import ctypes
+import math
 
 import torch
 
@@ -99,30 +100,53 @@ def _workspace(device, nbytes):
     return ws
 
 
-def coarse_forward(feat_a, feat_b, ksize, ncn, want_delta=True, out_corr=None, out_delta=None):
-    """forward_coarse_match for one pair.  feat_*: [C,h,w] fp32 GPU.  Returns (corr [hA',wA',hB',wB'],
-    packed delta uint8 of the same shape or None); `out_*` let the caller provide (contiguous) outputs."""
+# Upper bound on the coarse-stage scratch of one call: a batch whose pairs need more is processed in groups
+# (the hidden volume of the consensus net is 184 MB per 480x640 pair, 2.9 GB per 960x1280 pair).
+COARSE_WORKSPACE_LIMIT = 16 << 30
+
+
+def coarse_forward_batch(feat_a, feat_b, ksize, ncn, want_delta=True, out_corr=None, out_delta=None):
+    """forward_coarse_match for the B pairs of feat_a [B,C,hA,wA] / feat_b [B,C,hB,wB] (fp32 GPU) in one launch
+    per kernel.  Returns (corr [B,hA',wA',hB',wB'], packed delta uint8 of the same shape or None); `out_*` let
+    the caller provide (contiguous) outputs."""
     feat_a, feat_b = _f32c(feat_a, "feat_a"), _f32c(feat_b, "feat_b")
-    c, ha, wa = feat_a.shape
-    c2, hb, wb = feat_b.shape
+    if feat_a.dim() != 4 or feat_b.dim() != 4 or feat_a.shape[0] != feat_b.shape[0]:
+        raise ValueError("coarse_forward_batch expects [B,C,h,w] feature maps with equal B")
+    nb, c, ha, wa = feat_a.shape
+    _, c2, hb, wb = feat_b.shape
     if c != c2:
         raise ValueError("channel mismatch between the two feature maps")
     dev = feat_a.device
+    k = max(ksize, 1)
+    shape = (nb, ha // k, wa // k, hb // k, wb // k)
+    corr = out_corr if out_corr is not None else torch.empty(shape, dtype=torch.float32, device=dev)
+    delta = None
+    if ksize > 1 and want_delta:
+        delta = out_delta if out_delta is not None else torch.empty(shape, dtype=torch.uint8, device=dev)
+    assert corr.is_contiguous() and corr.numel() == math.prod(shape) and corr.dtype == torch.float32
+    assert delta is None or (delta.is_contiguous() and delta.numel() == math.prod(shape) and delta.dtype == torch.uint8)
+    if nb == 0:
+        return corr, delta
     with torch.cuda.device(dev):
-        nbytes = _lib.p2p_coarse_workspace_bytes(c, ha, wa, hb, wb, ksize)
-        ws = _workspace(dev, max(nbytes, 256))
-        k = max(ksize, 1)
-        shape = (ha // k, wa // k, hb // k, wb // k)
-        corr = out_corr if out_corr is not None else torch.empty(shape, dtype=torch.float32, device=dev)
-        delta = None
-        if ksize > 1 and want_delta:
-            delta = out_delta if out_delta is not None else torch.empty(shape, dtype=torch.uint8, device=dev)
-        assert corr.is_contiguous() and tuple(corr.shape) == shape and corr.dtype == torch.float32
-        assert delta is None or (delta.is_contiguous() and tuple(delta.shape) == shape and delta.dtype == torch.uint8)
-        _lib.check(_lib.p2p_coarse_forward(feat_a.data_ptr(), feat_b.data_ptr(), c, ha, wa, hb, wb, ksize, ncn.handle,
-                                           corr.data_ptr(), delta.data_ptr() if delta is not None else None,
-                                           ws.data_ptr(), ws.numel(), _stream()), "p2p_coarse_forward")
+        per_pair = _lib.p2p_coarse_workspace_bytes(c, ha, wa, hb, wb, ksize)
+        if per_pair == 0:
+            raise ValueError("coarse_forward: bad sizes")
+        pairs = max(1, min(nb, COARSE_WORKSPACE_LIMIT // per_pair))
+        ws = _workspace(dev, pairs * per_pair)
+        _lib.check(_lib.p2p_coarse_forward_batch(feat_a.data_ptr(), feat_b.data_ptr(), nb, c, ha, wa, hb, wb, ksize,
+                                                 ncn.handle, corr.data_ptr(),
+                                                 delta.data_ptr() if delta is not None else None,
+                                                 ws.data_ptr(), ws.numel(), _stream()), "p2p_coarse_forward_batch")
     return corr, delta
+
+
+def coarse_forward(feat_a, feat_b, ksize, ncn, want_delta=True, out_corr=None, out_delta=None):
+    """forward_coarse_match for one pair.  feat_*: [C,h,w] fp32 GPU.  Returns (corr [hA',wA',hB',wB'],
+    packed delta uint8 of the same shape or None)."""
+    corr, delta = coarse_forward_batch(feat_a[None], feat_b[None], ksize, ncn, want_delta,
+                                       out_corr[None] if out_corr is not None else None,
+                                       out_delta[None] if out_delta is not None else None)
+    return corr[0], (delta[0] if delta is not None else None)
 
 
 def delta_unpack(delta, ksize):
@@ -134,23 +158,39 @@ def delta_unpack(delta, ksize):
     return out[0], out[1], out[2], out[3]
 
 
-def coarse_matches(corr, delta, ksize, upsample, center=True, out_matches=None, out_scores=None):
-    """cal_coarse_matches for one pair: ([nB+nA,4] int64 pixel matches, [nB+nA] fp32 scores)."""
+def coarse_matches_batch(corr, delta, ksize, upsample, center=True, out_matches=None, out_scores=None):
+    """cal_coarse_matches for B pairs: corr [B,hA',wA',hB',wB'] (+ packed delta of the same shape or None) ->
+    ([B,nB+nA,4] int64 pixel matches, [B,nB+nA] fp32 scores)."""
     corr = _f32c(corr, "corr4d")
-    ha, wa, hb, wb = corr.shape
+    if corr.dim() != 5:
+        raise ValueError("coarse_matches_batch expects corr4d of shape [B,hA,wA,hB,wB]")
+    nb, ha, wa, hb, wb = corr.shape
     n = ha * wa + hb * wb
     dev = corr.device
-    matches = out_matches if out_matches is not None else torch.empty((n, 4), dtype=torch.int64, device=dev)
-    scores = out_scores if out_scores is not None else torch.empty((n,), dtype=torch.float32, device=dev)
-    assert matches.is_contiguous() and tuple(matches.shape) == (n, 4) and matches.dtype == torch.int64
-    assert scores.is_contiguous() and tuple(scores.shape) == (n,) and scores.dtype == torch.float32
+    matches = out_matches if out_matches is not None else torch.empty((nb, n, 4), dtype=torch.int64, device=dev)
+    scores = out_scores if out_scores is not None else torch.empty((nb, n), dtype=torch.float32, device=dev)
+    assert matches.is_contiguous() and matches.numel() == nb * n * 4 and matches.dtype == torch.int64
+    assert scores.is_contiguous() and scores.numel() == nb * n and scores.dtype == torch.float32
     if delta is not None:
         delta = delta.contiguous()
+        if delta.dtype != torch.uint8 or delta.numel() != corr.numel():
+            raise ValueError("delta must be the packed uint8 volume with the shape of corr4d")
+    if nb == 0:
+        return matches, scores
     with torch.cuda.device(dev):
-        _lib.check(_lib.p2p_coarse_matches(corr.data_ptr(), delta.data_ptr() if delta is not None else None,
-                                           ha, wa, hb, wb, ksize, upsample, int(bool(center)),
-                                           matches.data_ptr(), scores.data_ptr(), _stream()), "p2p_coarse_matches")
+        _lib.check(_lib.p2p_coarse_matches_batch(corr.data_ptr(), delta.data_ptr() if delta is not None else None, nb,
+                                                 ha, wa, hb, wb, ksize, upsample, int(bool(center)),
+                                                 matches.data_ptr(), scores.data_ptr(), _stream()),
+                   "p2p_coarse_matches_batch")
     return matches, scores
+
+
+def coarse_matches(corr, delta, ksize, upsample, center=True, out_matches=None, out_scores=None):
+    """cal_coarse_matches for one pair: ([nB+nA,4] int64 pixel matches, [nB+nA] fp32 scores)."""
+    m, sc = coarse_matches_batch(corr[None], delta[None] if delta is not None else None, ksize, upsample, center,
+                                 out_matches[None] if out_matches is not None else None,
+                                 out_scores[None] if out_scores is not None else None)
+    return m[0], sc[0]
 
 
 def _pyramid(levels):

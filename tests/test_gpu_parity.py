@@ -106,6 +106,48 @@ def test_coarse_vs_oracle(hw, ksize, dev, ops, weights):
     assert torch.allclose(s.cpu(), rs, rtol=1e-5)
 
 
+@pytest.mark.parametrize("tile", ["2,4,2,2,128", "3,5,3,3,256", "4,6,2,4,128", "2,4,3,30,256", "5,10,2,1,256"])
+def test_consensus_layer2_tilings(tile, dev, ops, weights, monkeypatch):
+    """The second consensus layer marches along the first axis in chunks of `ta` slices; the tile is normally picked
+    from the volume and batch size.  Force several (tb,tc,tdr,ta,threads) shapes, including chunks that do not
+    divide the axis and d-tiles narrower than the volume, on a volume small enough for the oracle."""
+    sd, ncn, _, _ = weights
+    monkeypatch.setenv("P2P_NC2_TILE", tile)
+    H, W = 112, 176                                     # pooled volume 7 x 11 x 7 x 11
+    p1, p2 = synthetic.make_correlated_pyramids(321, H, W)
+    o_ncn, _, _ = orc.split_params(sd)
+    rc, rd = orc.coarse_forward(p1[4], p2[4], 2, o_ncn)
+    corr, _ = ops.coarse_forward(p1[4].to(dev), p2[4].to(dev), 2, ncn)
+    np.testing.assert_allclose(corr.cpu().numpy(), rc.numpy(), rtol=2e-4, atol=1e-7)
+    # a wider volume (k = 1: 14 x 22 x 14 x 22, last axis not a multiple of 4 -> row-wise staging)
+    rc1, _ = orc.coarse_forward(p1[4], p2[4], 1, o_ncn)
+    corr1, _ = ops.coarse_forward(p1[4].to(dev), p2[4].to(dev), 1, ncn)
+    np.testing.assert_allclose(corr1.cpu().numpy(), rc1.numpy(), rtol=2e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("ksize", [1, 2])
+def test_coarse_batch_equals_per_pair(ksize, dev, ops, weights, monkeypatch):
+    """p2p_coarse_forward_batch / p2p_coarse_matches_batch over B pairs == B single-pair calls, bit for bit, also
+    when the workspace only holds some of the pairs at a time (the library then works through the batch in groups)."""
+    sd, ncn, _, _ = weights
+    H, W, B = 96, 128, 5
+    pairs = [synthetic.make_correlated_pyramids(500 + i, H, W) for i in range(B)]
+    fa = torch.stack([p[0][4] for p in pairs]).to(dev)
+    fb = torch.stack([p[1][4] for p in pairs]).to(dev)
+    singles = [ops.coarse_forward(fa[i], fb[i], ksize, ncn) for i in range(B)]
+    per_pair = ops._lib.p2p_coarse_workspace_bytes(fa.shape[1], fa.shape[2], fa.shape[3], fb.shape[2], fb.shape[3], ksize)
+    for limit in (ops.COARSE_WORKSPACE_LIMIT, 2 * per_pair + 1):
+        monkeypatch.setattr(ops, "COARSE_WORKSPACE_LIMIT", limit)
+        corr, delta = ops.coarse_forward_batch(fa, fb, ksize, ncn)
+        m, sc = ops.coarse_matches_batch(corr, delta, ksize, 8, True)
+        for i in range(B):
+            assert torch.equal(corr[i], singles[i][0]), (limit, i)
+            if ksize > 1:
+                assert torch.equal(delta[i], singles[i][1]), (limit, i)
+            m1, s1 = ops.coarse_matches(singles[i][0], singles[i][1], ksize, 8, True)
+            assert torch.equal(m[i], m1) and torch.equal(sc[i], s1), (limit, i)
+
+
 # ------------------------------------------------------------------------------------------ fine
 def _compare_matches(got, ref, tol=COORD_TOL):
     diff = (got - ref).abs().max().item() if got.numel() else 0.0
