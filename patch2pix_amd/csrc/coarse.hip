@@ -256,10 +256,10 @@ __global__ __launch_bounds__(256) void mm_apply_kernel(const float *X, int nA, i
 struct Vol { int d0, d1, d2, d3; };
 
 // layer 1: X (mutual matching already applied) -> H1[32][nA][nB], bias + ReLU.
-// Work-group: one a, L1_TB rows b, L1_Q consecutive B cells q = c*d3 + d.  A wave therefore stores 256
+// Work-group: one a, L1_TB rows b, L1_Q consecutive B cells q = c*d3 + d.  A wave therefore stores runs of 256
 // contiguous bytes per hidden channel (the 184 MB of H1 per 480x640 pair is the kernel's real cost), for any
 // d3.  The input halo is staged as whole (c) rows: [3 a][L1_TB+2 b][nrc c][d3+2] floats.
-constexpr int L1_TB = 4, L1_Q = 64;
+constexpr int L1_TB = 4, L1_R = 2, L1_Q = 64 * L1_R;      // a thread owns L1_R cells 64 apart: one weight fetch feeds both
 static int l1_rows(int d3) { return (L1_Q - 2) / d3 + 2 + 2; }      // c-rows L1_Q consecutive cells can touch, + halo
 
 __global__ __launch_bounds__(256) void nc_layer1_kernel(const float *__restrict__ X, Vol v, const float *__restrict__ w1cat,
@@ -288,36 +288,51 @@ __global__ __launch_bounds__(256) void nc_layer1_kernel(const float *__restrict_
             tile1[r * W + col] = (rok && col >= 1 && col <= v.d3) ? src[col] : 0.f;
     }
     __syncthreads();
-    const int tb = wave, cb = q0 + lane;
-    const int c = cb / v.d3, d = cb - c * v.d3;
-    const int ib = b0 + tb;
-    const bool active = cb < nB && ib < v.d1;
-    float acc[32];
+    const int tb = wave, ib = b0 + tb;
+    int cb[L1_R], boff[L1_R];
+    bool active[L1_R];
 #pragma unroll
-    for (int o = 0; o < 32; ++o) acc[o] = 0.f;
-    if (active) {
-        const float *base = tile1 + (tb * nrc + (c - c_lo - 1)) * W + d;
-#ifdef P2P_NC1_SKIP_COMPUTE
-        for (int da = 0; da < (v.d0 < 0 ? 3 : 0); ++da)
-#else
-        for (int da = 0; da < 3; ++da)
-#endif
-            for (int db = 0; db < 3; ++db) {
-                const float *tp = base + (da * HB + db) * nrc * W;
-                const float *wp = w1cat + (da * 3 + db) * 9 * 32;
-#pragma unroll
-                for (int dc = 0; dc < 3; ++dc)
-#pragma unroll
-                    for (int dd = 0; dd < 3; ++dd) {
-                        const float x = tp[dc * W + dd];
-#pragma unroll
-                        for (int o = 0; o < 32; ++o) acc[o] = fmaf(x, wp[(dc * 3 + dd) * 32 + o], acc[o]);
-                    }
-            }
-        const size_t pos = (size_t)(a * v.d1 + ib) * nB + cb;
-#pragma unroll
-        for (int o = 0; o < 32; ++o) H1[o * nAB + pos] = fmaxf(acc[o] + b1cat[o], 0.f);
+    for (int h = 0; h < L1_R; ++h) {
+        cb[h] = q0 + 64 * h + lane;
+        const int c = cb[h] / v.d3, d = cb[h] - c * v.d3;
+        active[h] = cb[h] < nB && ib < v.d1;
+        boff[h] = active[h] ? (tb * nrc + (c - c_lo - 1)) * W + d : 0;      // inactive cells read cell 0 and store nothing
     }
+    float acc[L1_R][32];
+#pragma unroll
+    for (int h = 0; h < L1_R; ++h)
+#pragma unroll
+        for (int o = 0; o < 32; ++o) acc[h][o] = 0.f;
+#ifdef P2P_NC1_SKIP_COMPUTE
+    for (int da = 0; da < (v.d0 < 0 ? 3 : 0); ++da)
+#else
+    for (int da = 0; da < 3; ++da)
+#endif
+        for (int db = 0; db < 3; ++db) {
+            const float *tp = tile1 + (da * HB + db) * nrc * W;
+            const float *wp = w1cat + (da * 3 + db) * 9 * 32;
+#pragma unroll
+            for (int dc = 0; dc < 3; ++dc)
+#pragma unroll
+                for (int dd = 0; dd < 3; ++dd) {
+                    float x[L1_R];
+#pragma unroll
+                    for (int h = 0; h < L1_R; ++h) x[h] = tp[boff[h] + dc * W + dd];
+#pragma unroll
+                    for (int o = 0; o < 32; ++o) {
+                        const float w = wp[(dc * 3 + dd) * 32 + o];
+#pragma unroll
+                        for (int h = 0; h < L1_R; ++h) acc[h][o] = fmaf(x[h], w, acc[h][o]);
+                    }
+                }
+        }
+#pragma unroll
+    for (int h = 0; h < L1_R; ++h)
+        if (active[h]) {
+            const size_t pos = (size_t)(a * v.d1 + ib) * nB + cb[h];
+#pragma unroll
+            for (int o = 0; o < 32; ++o) H1[o * nAB + pos] = fmaxf(acc[h][o] + b1cat[o], 0.f);
+        }
 }
 
 // layer 2: Y = relu(b2 + sum_{c<16} W2*H1[c]) + relu(b2 + sum_{c<16} W2^T*H1[16+c])
