@@ -2,6 +2,7 @@
 """Summarise rocprofv3 --pmc result databases (one per counter group) into text + the regress traffic json.
 usage: python tools/pmc_summary.py OUT_TXT OUT_JSON db1 db2 ..."""
 import json
+import os
 import sqlite3
 import sys
 
@@ -30,8 +31,9 @@ def main(out_txt, out_json, dbs):
             act = rg["GRBM_GUI_ACTIVE"]
             clk = act[1] / 8 / (act[2] * 1e-9) / 1e9
             mf = rg["SQ_VALU_MFMA_BUSY_CYCLES"][1] / 1024 / (act[1] / 8) if "SQ_VALU_MFMA_BUSY_CYCLES" in rg else None
-            json.dump({"kernel": k.split("::")[-1], "proposals_per_launch": 2000,
-                       "launch": "2000 proposals (5 pairs x 400), 2 levels", "hbm_bytes_per_launch": fetch + write,
+            pairs = int(os.environ.get("P2P_PAIRS_PER_STEP", "16"))      # bench.py default: 16 pairs x 400 proposals
+            json.dump({"kernel": k.split("::")[-1], "proposals_per_launch": pairs * 400,
+                       "launch": f"{pairs * 400} proposals ({pairs} pairs x 400), 2 levels", "hbm_bytes_per_launch": fetch + write,
                        "fetch_bytes_corrected_x2": fetch, "write_bytes": write, "effective_clock_ghz": clk,
                        "mfma_busy_fraction": mf, "source": out_txt}, open(out_json, "w"), indent=1)
 
