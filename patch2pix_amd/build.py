@@ -69,5 +69,29 @@ def build(force=False, verbose=True):
     return LIB
 
 
+ROOT = os.path.dirname(os.path.dirname(CSRC))
+EXAMPLE_SRC = os.path.join(ROOT, "examples", "cabi_coarse.c")
+EXAMPLE_BIN = os.path.join(ROOT, "examples", "_build", "cabi_coarse")
+
+
+def build_examples(force=False, verbose=True):
+    """examples/cabi_coarse.c: the C ABI used from plain C (gcc, C11) -- proves the header is C and the library
+    needs nothing from Python.  Linked against the in-tree library with a relative rpath."""
+    build(force=False, verbose=verbose)
+    if (not force and os.path.exists(EXAMPLE_BIN) and os.path.getmtime(EXAMPLE_BIN) >= max(
+            os.path.getmtime(EXAMPLE_SRC), os.path.getmtime(LIB))):
+        return EXAMPLE_BIN
+    os.makedirs(os.path.dirname(EXAMPLE_BIN), exist_ok=True)
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [os.environ.get("CC", "gcc"), "-std=c11", "-O2", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", f"-I{rocm}/include",
+           "-I" + os.path.join(ROOT, "include"), EXAMPLE_SRC, "-o", EXAMPLE_BIN, "-L" + CSRC, "-lp2p_hip",
+           f"-L{rocm}/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN/../../patch2pix_amd/csrc", f"-Wl,-rpath,{rocm}/lib"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return EXAMPLE_BIN
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_examples(force="--force" in sys.argv)

@@ -65,3 +65,29 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("test-oracle", ""), f"{f} mentions the oracle"
+
+
+def test_batch_argument_errors(lib):
+    """The batch entry points validate before touching the device (status -1 = P2P_EINVAL, -3 = unsupported)."""
+    assert lib.p2p_coarse_forward_batch(1, 1, 0, 256, 8, 8, 8, 8, 2, 1, 1, None, 1, 1 << 30, None) == -1     # batch 0
+    assert b"batch" in lib.p2p_last_error()
+    assert lib.p2p_coarse_forward_batch(1, 1, 2, 256, 8, 8, 8, 8, 3, 1, 1, None, 1, 1 << 30, None) == -3     # ksize 3
+    assert lib.p2p_coarse_forward_batch(1, 1, 2, 256, 8, 8, 8, 8, 2, 1, 1, None, 1, 64, None) != 0           # workspace < one pair
+    assert b"workspace" in lib.p2p_last_error()
+    assert lib.p2p_coarse_matches_batch(1, None, 2, 4, 4, 4, 4, 2, 8, 1, 1, 1, None) == -1                   # delta missing, ksize 2
+    assert lib.p2p_coarse_matches_batch(None, None, 2, 4, 4, 4, 4, 1, 8, 1, 1, 1, None) == -1
+
+
+def test_plain_c_example_builds_and_reports_missing_device(tmp_path):
+    """examples/cabi_coarse.c is C11 built by gcc against include/p2p_hip.h and the in-tree library: the header is
+    valid C and the library needs nothing from Python.  Without a GPU the program must say so (exit code 3)."""
+    import subprocess
+    import torch
+    from patch2pix_amd import build
+    exe = build.build_examples(verbose=False)
+    assert os.path.exists(exe)
+    res = subprocess.run([exe], capture_output=True, text=True)
+    assert res.returncode == 2 and "usage" in res.stderr
+    if not torch.cuda.is_available():
+        res = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+        assert res.returncode == 3 and "no HIP device" in res.stderr
