@@ -8,7 +8,6 @@ reference checkpoints (`extract.*` keys, utils/train/helper.py:10-17) load uncha
 `layer4.*` keys of a checkpoint are never used by the path (reference
 networks/patch2pix.py:72-74 freezes them as "never used") and are skipped on load.
 """
-import torch
 import torch.nn as nn
 import torch.nn.functional as F
 

@@ -3,7 +3,6 @@ from (oracle/make_golden.py) and verify the recorded input checksum."""
 import os
 
 import numpy as np
-import torch
 
 from patch2pix_amd.utils import synthetic
 

@@ -2,7 +2,7 @@
 PIL load + resize, backbone on PyTorch-ROCm, HIP matching path, D2H."""
 import os, sys, time, tempfile
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-import numpy as np, torch
+import torch
 from PIL import Image
 from patch2pix_amd.utils import synthetic
 from patch2pix_amd.utils.eval import model_helper
