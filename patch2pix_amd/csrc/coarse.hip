@@ -264,7 +264,7 @@ static int l1_rows(int d3) { return (L1_Q - 2) / d3 + 2 + 2; }      // c-rows L1
 
 __global__ __launch_bounds__(256) void nc_layer1_kernel(const float *__restrict__ X, Vol v, const float *__restrict__ w1cat,
                                                         const float *__restrict__ b1cat, float *__restrict__ H1, size_t sWs) {
-    extern __shared__ float tile1[];
+    P2P_DYN_SHARED(float, tile1);
     X += blockIdx.z * sWs;
     H1 += blockIdx.z * sWs;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -388,7 +388,7 @@ template <bool FULLROW>
 __global__ __launch_bounds__(256) void nc_layer2_kernel(const float *__restrict__ H1, Vol v, NcTile t,
                                                         const float *__restrict__ w2m, float b2,
                                                         float *__restrict__ Y, size_t sWs) {
-    extern __shared__ __attribute__((aligned(16))) float tile2[];      // [2][(tb+2)*(tc+2)][rs], then int rowoff[]
+    P2P_DYN_SHARED(float, tile2);      // [2][(tb+2)*(tc+2)][rs], then int rowoff[]
     H1 += blockIdx.z * sWs + (size_t)blockIdx.y * 16 * ((size_t)v.d0 * v.d1 * v.d2 * v.d3);      // this branch's 16 channels
     Y += blockIdx.z * sWs;
     w2m += blockIdx.y * 16 * 81;

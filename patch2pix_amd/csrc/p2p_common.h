@@ -32,6 +32,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Two constructs the host-side kernel emulator of the test-suite (tests/hipemu) has to see through; for hipcc
+// they expand to exactly the code they replace.
+#ifndef P2P_OPAQUE                 // make a VGPR value opaque to the optimiser (stops hoisting of lane-only index math)
+#define P2P_OPAQUE(v) asm volatile("" : "+v"(v))
+#endif
+#ifndef P2P_DYN_SHARED             // the dynamic LDS allocation of a kernel, 16-byte aligned
+#define P2P_DYN_SHARED(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
+#endif
+
 // Check the launch that was just issued (asynchronous errors surface at the next sync).
 static inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();

@@ -60,7 +60,7 @@ constexpr size_t LDS_BYTES = size_t(LDS_FLOATS) * 4;
     }
 
 __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    P2P_DYN_SHARED(float, smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -44,7 +44,7 @@ __device__ __forceinline__ int patch_cell(int origin, int p, int j, int dim) {
 // misc[8..11] current proposal (in: base of the offsets, out: regressed match).
 __device__ __forceinline__ void fc_tail_parse(const RegDev &R, const ItemDev &I, const RegressArgs &args, int lvl, int prop,
                                               int tid, const float *V, float *F1, float *F2, float *misc) {
-    asm volatile("" : "+v"(tid));      // keep the per-lane weight offsets from being hoisted out of the level loop (and spilled)
+    P2P_OPAQUE(tid);      // keep the per-lane weight offsets from being hoisted out of the level loop (and spilled)
     {   // 512 outputs x 512 inputs: 32 weight loads (16 B each) in flight per thread
         const f32x4 *w = (const f32x4 *)R.fc1t + tid;
         float s = 0.f;

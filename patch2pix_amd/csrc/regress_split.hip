@@ -120,7 +120,7 @@ __device__ __forceinline__ float sumsq8(const f32x4 &h, const f32x4 &l, float ss
 #endif
 
 __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
+    P2P_DYN_SHARED(unsigned char, smb);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
         // thread id, and without this the compiler hoists all of it out of the level loop and spills it
         // (scratch must stay at zero, see build.py).
         int tidv = tid;
-        asm volatile("" : "+v"(tidv));
+        P2P_OPAQUE(tidv);
 
         // ------------------------------------------------------------ zero cells of the tiles
         if (tidv < 2 * 2 * 3) {

@@ -1,0 +1,34 @@
+"""TEST INFRASTRUCTURE: compile the kernel sources of patch2pix_amd/csrc for the HOST against the HIP stand-in in
+this directory (tests/hipemu/hip/hip_runtime.h) -> tests/hipemu/_build/libp2p_emu.so, the same C ABI operating on
+host pointers.  Only tests/test_kernels_emulated.py loads it; the product never does."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "patch2pix_amd", "csrc")
+OUT = os.path.join(HERE, "_build", "libp2p_emu.so")
+SOURCES = ["api.hip", "coarse.hip", "regress.hip", "regress_split.hip"]
+
+
+def build(force=False, verbose=False):
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    deps += [os.path.join(HERE, "hipemu.cpp"), os.path.join(HERE, "hip", "hip_runtime.h"),
+             os.path.join(ROOT, "include", "p2p_hip.h")]
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    cxx = os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+    cmd = [cxx, "-std=c++17", "-O2", "-g0", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-I" + HERE,
+           "-Wno-unused-value", "-Wno-unknown-attributes", "-o", OUT]
+    for s in SOURCES:
+        cmd += ["-x", "c++", os.path.join(CSRC, s)]
+    cmd += ["-x", "c++", os.path.join(HERE, "hipemu.cpp")]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,115 @@
+"""TEST INFRASTRUCTURE: load tests/hipemu/_build/libp2p_emu.so (the kernel sources compiled for the host, see
+build_emu.py) with the prototypes of the real binding, plus small helpers that call it on CPU tensors."""
+import ctypes
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import build_emu  # noqa: E402
+
+from patch2pix_amd import _lib as real  # noqa: E402  (prototypes only; nothing of the real library is called)
+
+
+def load():
+    emu = ctypes.CDLL(build_emu.build())
+    for name in real.EXPORTS:
+        src, dst = getattr(real.lib, name), getattr(emu, name)
+        dst.argtypes, dst.restype = src.argtypes, src.restype
+    return emu
+
+
+def check(emu, status, what):
+    if status != 0:
+        raise RuntimeError(f"{what}: {emu.p2p_last_error().decode()}")
+
+
+def ptr(t):
+    assert t is None or (t.device.type == "cpu" and t.is_contiguous())
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def ncn_create(emu, sd):
+    keep = [sd[k].detach().float().contiguous() for k in
+            ("ncn.conv.0.weight", "ncn.conv.0.bias", "ncn.conv.2.weight", "ncn.conv.2.bias")]
+    h = ctypes.c_void_p()
+    check(emu, emu.p2p_ncn_create(*[t.data_ptr() for t in keep], ctypes.byref(h)), "p2p_ncn_create")
+    return h
+
+
+def coarse_forward_batch(emu, ncn, fa, fb, ksize, ws_pairs=None):
+    """fa, fb: [B,C,h,w] fp32 CPU -> (corr [B,hA',wA',hB',wB'], delta uint8 or None)."""
+    fa, fb = fa.contiguous(), fb.contiguous()
+    nb, c, ha, wa = fa.shape
+    _, _, hb, wb = fb.shape
+    k = max(ksize, 1)
+    shape = (nb, ha // k, wa // k, hb // k, wb // k)
+    corr = torch.empty(shape, dtype=torch.float32)
+    delta = torch.empty(shape, dtype=torch.uint8) if ksize > 1 else None
+    per_pair = emu.p2p_coarse_workspace_bytes(c, ha, wa, hb, wb, ksize)
+    ws = torch.empty((ws_pairs or nb) * per_pair + 256, dtype=torch.uint8)
+    base = (ws.data_ptr() + 255) & ~255
+    check(emu, emu.p2p_coarse_forward_batch(ptr(fa), ptr(fb), nb, c, ha, wa, hb, wb, ksize, ncn, ptr(corr), ptr(delta),
+                                            ctypes.c_void_p(base), (ws_pairs or nb) * per_pair, None),
+          "p2p_coarse_forward_batch")
+    return corr, delta
+
+
+def coarse_matches_batch(emu, corr, delta, ksize, upsample, center=True):
+    nb, ha, wa, hb, wb = corr.shape
+    n = ha * wa + hb * wb
+    m = torch.empty((nb, n, 4), dtype=torch.int64)
+    s = torch.empty((nb, n), dtype=torch.float32)
+    check(emu, emu.p2p_coarse_matches_batch(ptr(corr), ptr(delta), nb, ha, wa, hb, wb, ksize, upsample, int(center),
+                                            ptr(m), ptr(s), None), "p2p_coarse_matches_batch")
+    return m, s
+
+
+def regressor_create(emu, sd, mode):
+    """sd: sub-state_dict of one FeatRegressNet ('conv.0.weight', ...); mode 'f32' | 'bf16x2'."""
+    keep = {k: v.detach().float().contiguous() for k, v in sd.items() if v.is_floating_point()}
+    p = real.RegressorParams()
+
+    def bn(prefix):
+        return real.BnParams(keep[prefix + ".weight"].data_ptr(), keep[prefix + ".bias"].data_ptr(),
+                             keep[prefix + ".running_mean"].data_ptr(), keep[prefix + ".running_var"].data_ptr())
+
+    p.conv1_w = keep["conv.0.weight"].data_ptr(); p.bn1 = bn("conv.1")
+    p.conv2_w = keep["conv.2.weight"].data_ptr(); p.bn2 = bn("conv.3")
+    p.fc1_w = keep["fc.0.weight"].data_ptr(); p.fc1_b = keep["fc.0.bias"].data_ptr(); p.bnf1 = bn("fc.1")
+    p.fc2_w = keep["fc.3.weight"].data_ptr(); p.fc2_b = keep["fc.3.bias"].data_ptr(); p.bnf2 = bn("fc.4")
+    p.fc3_w = keep["fc.6.weight"].data_ptr(); p.fc3_b = keep["fc.6.bias"].data_ptr()
+    h = ctypes.c_void_p()
+    check(emu, emu.p2p_regressor_create(ctypes.byref(p), ctypes.byref(h)), "p2p_regressor_create")
+    check(emu, emu.p2p_regressor_set_mode(h, real.REGRESS_MODES[mode]), "p2p_regressor_set_mode")
+    return h
+
+
+def regress(emu, reg1, reg2, pyr1, pyr2, proposals):
+    """One pair through p2p_regress_batch: pyr*: the 4 maps of feat_idx [0,1,2,3] (CPU fp32), proposals [n,4]
+    int64 or float32.  Returns dict matches1/probs1/raw1 (+ *2 with reg2)."""
+    def pyramid(levels):
+        lv = [t.contiguous() for t in levels]
+        q = real.Pyramid()
+        for j in range(4):
+            q.level[j] = lv[j].data_ptr()
+        q.height, q.width = lv[0].shape[-2:]
+        return q, lv
+    pa, ka = pyramid(pyr1)
+    pb, kb = pyramid(pyr2)
+    n = proposals.shape[0]
+    proposals = proposals.contiguous()
+    out = {k: torch.empty((n, c) if c > 1 else (n,), dtype=torch.float32)
+           for k, c in (("matches1", 4), ("probs1", 1), ("raw1", 5), ("matches2", 4), ("probs2", 1), ("raw2", 5))}
+    two = reg2 is not None
+    arr_a, arr_b = (real.Pyramid * 1)(pa), (real.Pyramid * 1)(pb)
+    cnt = (ctypes.c_int * 1)(n)
+    check(emu, emu.p2p_regress_batch(reg1, reg2 if two else None, 1, arr_a, arr_b, cnt, proposals.data_ptr(),
+                                     int(proposals.is_floating_point()), out["matches1"].data_ptr(),
+                                     out["probs1"].data_ptr(), out["raw1"].data_ptr(),
+                                     out["matches2"].data_ptr() if two else None, out["probs2"].data_ptr() if two else None,
+                                     out["raw2"].data_ptr() if two else None, None), "p2p_regress_batch")
+    del ka, kb
+    return out

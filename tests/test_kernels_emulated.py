@@ -1,0 +1,123 @@
+"""The HIP kernels' own code, executed on the CPU by the test-suite's HIP stand-in (tests/hipemu: the unmodified
+.hip sources compiled for x86, work-items as fibers, wave64 collectives and the two MFMA shapes emulated) and checked
+against the golden vectors of the reference and against the oracle.
+
+This is TEST INFRASTRUCTURE for the index arithmetic of the kernels when no GPU is at hand; the emulated library is
+built and loaded only here.  The product has no CPU path (tests/test_cabi_exports.py::test_no_cpu_fallback), and the
+parity claims rest on the -m gpu tests, which run the same sources on the MI355X.
+Tolerances are those of tests/test_gpu_parity.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import p2p_oracle as orc
+from patch2pix_amd.utils import synthetic
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
+import emu_lib  # noqa: E402
+
+COORD_TOL, SCORE_TOL = 1e-3, 1e-5
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return emu_lib.load()
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return gu.state_dict(0)
+
+
+@pytest.fixture(scope="module")
+def ncn(emu, sd):
+    return emu_lib.ncn_create(emu, sd)
+
+
+@pytest.mark.parametrize("name", gu.COARSE_CASES)
+def test_coarse_stage_against_reference_golden(name, emu, ncn):
+    g = gu.load(name)
+    p1, p2 = gu.coarse_inputs(g)
+    ksize = int(g["ksize"])
+    corr, delta = emu_lib.coarse_forward_batch(emu, ncn, p1[4][None], p2[4][None], ksize)
+    np.testing.assert_allclose(corr[0].numpy(), g["corr4d"], rtol=2e-4, atol=1e-7)
+    if ksize > 1:
+        k, rd = ksize, g["delta4d"].astype(np.int64)
+        assert np.array_equal(delta[0].numpy(), (((rd[0] * k + rd[1]) * k + rd[2]) * k + rd[3]).reshape(delta[0].shape))
+    m, s = emu_lib.coarse_matches_batch(emu, corr, delta, ksize, 8)
+    assert np.array_equal(m[0].numpy(), g["all_matches"])
+    np.testing.assert_allclose(s[0].numpy(), g["all_scores"], rtol=2e-4)
+
+
+@pytest.mark.parametrize("tile", [None, "2,4,2,2,128", "3,5,3,3,256", "4,6,2,4,128", "2,4,3,30,256", "5,10,2,1,256"])
+def test_consensus_tilings_against_oracle(tile, emu, ncn, sd, monkeypatch):
+    """Forced (tb,tc,tdr,ta,threads) shapes of the second consensus layer: chunks of the march that do not divide
+    the first axis, d-tiles narrower than the volume, both staging paths (last axis 11 and 22: not multiples of 4;
+    the golden cases above cover the 16-byte path)."""
+    if tile:
+        monkeypatch.setenv("P2P_NC2_TILE", tile)
+    p1, p2 = synthetic.make_correlated_pyramids(321, 112, 176)
+    o_ncn, _, _ = orc.split_params(sd)
+    for ksize in (2, 1):
+        rc, _ = orc.coarse_forward(p1[4], p2[4], ksize, o_ncn)
+        corr, _ = emu_lib.coarse_forward_batch(emu, ncn, p1[4][None], p2[4][None], ksize)
+        np.testing.assert_allclose(corr[0].numpy(), rc.numpy(), rtol=2e-4, atol=1e-7)
+
+
+def test_coarse_batch_equals_single_pairs(emu, ncn):
+    """One launch per kernel for B pairs == B single-pair calls, bit for bit, also when the workspace only holds two
+    of the five pairs at a time."""
+    pairs = [synthetic.make_correlated_pyramids(500 + i, 64, 96) for i in range(5)]
+    fa = torch.stack([p[0][4] for p in pairs])
+    fb = torch.stack([p[1][4] for p in pairs])
+    singles = [emu_lib.coarse_forward_batch(emu, ncn, fa[i:i + 1], fb[i:i + 1], 2) for i in range(5)]
+    for ws_pairs in (5, 2):
+        corr, delta = emu_lib.coarse_forward_batch(emu, ncn, fa, fb, 2, ws_pairs=ws_pairs)
+        m, s = emu_lib.coarse_matches_batch(emu, corr, delta, 2, 8)
+        for i in range(5):
+            assert torch.equal(corr[i], singles[i][0][0]) and torch.equal(delta[i], singles[i][1][0])
+            m1, s1 = emu_lib.coarse_matches_batch(emu, singles[i][0], singles[i][1], 2, 8)
+            assert torch.equal(m[i], m1[0]) and torch.equal(s[i], s1[0])
+
+
+@pytest.mark.parametrize("mode", ["bf16x2", "f32"])
+def test_regressors_against_reference_golden(mode, emu, sd):
+    """Both regressor kernels (split-bf16 and exact fp32 MFMA) on the first proposals of the reference's
+    forward_fine_match golden: integer proposals through the mid regressor, float proposals through the fine one."""
+    sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+    regs = {"int_mid": emu_lib.regressor_create(emu, sub("regress_mid."), mode),
+            "float_fine": emu_lib.regressor_create(emu, sub("regress_fine."), mode)}
+    g = gu.load("fine_48x64")
+    p1, p2 = gu.fine_inputs(g)
+    n = 4
+    for tag, reg in regs.items():
+        props = torch.from_numpy(g[tag + "_in"][:n])
+        out = emu_lib.regress(emu, reg, None, p1[:4], p2[:4], props)
+        assert (out["matches1"] - torch.from_numpy(g[tag + "_matches"][:n])).abs().max() <= COORD_TOL
+        assert (out["probs1"] - torch.from_numpy(g[tag + "_probs"][:n])).abs().max() <= SCORE_TOL
+
+
+def test_regressor_chain_and_image_borders(emu, sd):
+    """Mid -> fine inside one launch (the fine patch is centred on the truncated mid match, its base is the
+    un-truncated one), with proposals on the image corners where every level of the patch clamps."""
+    sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+    mid = emu_lib.regressor_create(emu, sub("regress_mid."), "bf16x2")
+    fine = emu_lib.regressor_create(emu, sub("regress_fine."), "bf16x2")
+    H, W = 48, 64
+    p1, p2 = synthetic.make_pyramid(7, H, W), synthetic.make_pyramid(8, H, W)
+    props = torch.tensor([[0, 0, W, H], [W, H, 0, 0], [31, 17, 5, 40]])
+    _, mid_p, fine_p = orc.split_params(sd)
+    ref_mid, ref_midp, ref_raw = orc.fine_level(p1[:4], p2[:4], props, mid_p)
+    out = emu_lib.regress(emu, mid, fine, p1[:4], p2[:4], props)
+    assert (out["raw1"] - ref_raw).abs().max() < 5e-5
+    assert (out["matches1"] - ref_mid).abs().max() <= COORD_TOL
+    assert (out["probs1"] - ref_midp).abs().max() <= SCORE_TOL
+    # second level: the oracle is fed the kernel's own mid matches (a 1e-6 px wobble across an integer would move
+    # the whole fine patch by one pixel, networks/utils.py:19)
+    ref_fine, ref_finep, _ = orc.fine_level(p1[:4], p2[:4], out["matches1"], fine_p)
+    assert (out["matches2"] - ref_fine).abs().max() <= COORD_TOL
+    assert (out["probs2"] - ref_finep).abs().max() <= SCORE_TOL
