@@ -58,3 +58,27 @@ def test_synthetic_checkpoint_has_reference_schema():
     assert tuple(sd["ncn.conv.0.weight"].shape) == (3, 16, 1, 3, 3, 3)
     assert tuple(sd["regress_fine.conv.0.weight"].shape) == (512, 518, 3, 3)
     assert ck["regressor_config"].psize == [16, 16]
+
+
+def test_filter_coarse_property_based():
+    """Random match lists (many duplicates, pixel coordinates of any magnitude the packed 64-bit key supports and
+    beyond) against the oracle's restatement of networks/utils.py:38-72."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(1, 80), st.integers(1, 6), st.sampled_from([8, 1000, 65535, 70000]), st.booleans(),
+           st.sampled_from([0.0, 0.3, 0.9, 1.5]), st.integers(0, 2 ** 31 - 1))
+    def check(n, distinct, span, mutual, thres, seed):
+        g = torch.Generator().manual_seed(seed)
+        pool = torch.randint(0, span + 1, (distinct, 4), generator=g)
+        rows = pool[torch.randint(0, distinct, (n,), generator=g)]
+        scores = torch.rand(n, generator=g)
+        a, b = filter_coarse([rows], [scores], thres, mutual)
+        r, rs = orc.filter_coarse(rows, scores, thres, mutual)
+        assert torch.equal(a[0], r) and torch.equal(b[0], rs)
+        # rows come back in lexicographic order unless a keep-all fallback returned the input as it was
+        if a[0].shape[0] != n:
+            keys = [tuple(x) for x in a[0].tolist()]
+            assert keys == sorted(keys)
+
+    check()

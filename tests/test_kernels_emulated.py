@@ -121,3 +121,39 @@ def test_regressor_chain_and_image_borders(emu, sd):
     ref_fine, ref_finep, _ = orc.fine_level(p1[:4], p2[:4], out["matches1"], fine_p)
     assert (out["matches2"] - ref_fine).abs().max() <= COORD_TOL
     assert (out["probs2"] - ref_finep).abs().max() <= SCORE_TOL
+
+
+def test_regress_batch_items_of_different_sizes(emu, sd):
+    """p2p_regress_batch over items (pairs) of different image sizes, one of them empty == one call per item."""
+    import ctypes
+    from patch2pix_amd import _lib as real
+    sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+    mid = emu_lib.regressor_create(emu, sub("regress_mid."), "bf16x2")
+    sizes, counts = [(16, 24), (24, 16), (8, 8), (16, 16)], [2, 1, 0, 1]
+    g = torch.Generator().manual_seed(4)
+    pyr1 = [synthetic.make_pyramid(200 + i, h, w)[:4] for i, (h, w) in enumerate(sizes)]
+    pyr2 = [synthetic.make_pyramid(300 + i, h, w)[:4] for i, (h, w) in enumerate(sizes)]
+    props = [torch.stack([torch.randint(0, w + 1, (n,), generator=g), torch.randint(0, h + 1, (n,), generator=g),
+                          torch.randint(0, w + 1, (n,), generator=g), torch.randint(0, h + 1, (n,), generator=g)], 1)
+             for (h, w), n in zip(sizes, counts)]
+    n = sum(counts)
+    allp = torch.cat(props).contiguous()
+    arr_a, arr_b = (real.Pyramid * len(sizes))(), (real.Pyramid * len(sizes))()
+    keep = []
+    for i in range(len(sizes)):
+        for arr, pyr in ((arr_a, pyr1[i]), (arr_b, pyr2[i])):
+            lv = [t.contiguous() for t in pyr]
+            keep.append(lv)
+            for j in range(4):
+                arr[i].level[j] = lv[j].data_ptr()
+            arr[i].height, arr[i].width = lv[0].shape[-2:]
+    m = torch.empty((n, 4)); p = torch.empty((n,))
+    cnt = (ctypes.c_int * len(sizes))(*counts)
+    emu_lib.check(emu, emu.p2p_regress_batch(mid, None, len(sizes), arr_a, arr_b, cnt, allp.data_ptr(), 0, m.data_ptr(),
+                                             p.data_ptr(), None, None, None, None, None), "p2p_regress_batch")
+    start = 0
+    for i, c in enumerate(counts):
+        if c:
+            single = emu_lib.regress(emu, mid, None, pyr1[i], pyr2[i], props[i])
+            assert torch.equal(m[start:start + c], single["matches1"]) and torch.equal(p[start:start + c], single["probs1"])
+        start += c
