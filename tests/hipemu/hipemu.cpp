@@ -1,9 +1,8 @@
 // TEST INFRASTRUCTURE -- never part of the product (see hip/hip_runtime.h in this directory).
-// Fiber scheduler behind the host-side HIP stand-in: a work-group is a set of ucontext fibers on one OS thread,
+// Fiber scheduler behind the host-side HIP stand-in: a work-group is a set of fibers (own stacks, cooperative switch) on one OS thread,
 // barriers are cooperative yields, several OS threads each take whole work-groups.
 #include "hip/hip_runtime.h"
 
-#include <ucontext.h>
 
 #include <atomic>
 #include <thread>
@@ -23,8 +22,34 @@ struct Wave {
     int live = 0, waiting = 0;
 };
 
+// Minimal x86-64 (System V) cooperative context switch: callee-saved registers + stack pointer.  ucontext's
+// swapcontext makes two sigprocmask system calls per switch, which dominated the run time.
+extern "C" void hipemu_switch(void **save_sp, void *load_sp);
+asm(R"(
+    .text
+    .globl hipemu_switch
+    .type hipemu_switch, @function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipemu_switch, .-hipemu_switch
+)");
+
 struct Fiber {
-    ucontext_t uc;
+    void *sp = nullptr;
     Ctx ctx;
     State state = DONE;
     unsigned seq = 0;                     // collectives this lane has taken part in (selects the mailbox half)
@@ -36,7 +61,7 @@ struct Worker {                           // one per OS thread
     std::vector<Wave> waves;
     unsigned char *stacks = nullptr;     // malloc'ed, never zero-filled: pages are committed as fibers touch them
     unsigned char *lds = nullptr;
-    ucontext_t sched;
+    void *sched_sp = nullptr;
     Fiber *cur = nullptr;
     const std::function<void()> *body = nullptr;
     int live = 0, waiting_block = 0;
@@ -51,12 +76,13 @@ void trampoline() {
     f->state = DONE;
     w->live--;
     w->waves[f->wave].live--;
-    swapcontext(&f->uc, &w->sched);
+    hipemu_switch(&f->sp, w->sched_sp);
+    abort();      // a finished fiber is never resumed
 }
 
 void yield_to_scheduler() {
     Worker *w = tl_worker;
-    swapcontext(&w->cur->uc, &w->sched);
+    hipemu_switch(&w->cur->sp, w->sched_sp);
 }
 
 void run_block(Worker *w, Idx block, dim3 bdim, dim3 gdim) {
@@ -65,11 +91,15 @@ void run_block(Worker *w, Idx block, dim3 bdim, dim3 gdim) {
     for (int wv = 0; wv < nwaves; ++wv) { w->waves[wv].live = 0; w->waves[wv].waiting = 0; }
     for (int t = 0; t < n; ++t) {
         Fiber &f = w->fibers[t];
-        getcontext(&f.uc);
-        f.uc.uc_stack.ss_sp = w->stacks + (size_t)t * STACK_BYTES;
-        f.uc.uc_stack.ss_size = STACK_BYTES;
-        f.uc.uc_link = nullptr;
-        makecontext(&f.uc, trampoline, 0);
+        // fresh stack: six zeroed callee-saved slots, then the entry point as return address; the ABI wants
+        // rsp % 16 == 8 at function entry (as after a call), hence the extra slot above it
+        void **top = (void **)(w->stacks + (size_t)(t + 1) * STACK_BYTES);
+        top -= 2;
+        top[0] = (void *)trampoline;
+        top[1] = nullptr;
+        top -= 6;
+        for (int i = 0; i < 6; ++i) top[i] = nullptr;
+        f.sp = top;
         f.ctx.thread = Idx{(unsigned)t, 0, 0};
         f.ctx.block = block;
         f.ctx.bdim = bdim;
@@ -87,7 +117,7 @@ void run_block(Worker *w, Idx block, dim3 bdim, dim3 gdim) {
             Fiber &f = w->fibers[t];
             if (f.state != RUNNABLE) continue;
             w->cur = &f;
-            swapcontext(&w->sched, &f.uc);
+            hipemu_switch(&w->sched_sp, f.sp);
             progressed = true;
         }
         bool released = false;
