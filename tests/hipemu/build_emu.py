@@ -32,3 +32,20 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+
+
+def build_example(force=False, verbose=False):
+    """examples/cabi_coarse.c compiled as C++ against the stand-in and linked to the emulated library: the same
+    program as on the GPU box, runnable here."""
+    lib = build(force=force, verbose=verbose)
+    src = os.path.join(ROOT, "examples", "cabi_coarse.c")
+    exe = os.path.join(HERE, "_build", "cabi_coarse_emu")
+    if not force and os.path.exists(exe) and os.path.getmtime(exe) >= max(os.path.getmtime(src), os.path.getmtime(lib)):
+        return exe
+    cxx = os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+    cmd = [cxx, "-x", "c++", "-std=c++17", "-O1", "-I" + HERE, "-I" + os.path.join(ROOT, "include"), src, "-o", exe,
+           "-L" + os.path.dirname(lib), "-lp2p_emu", "-Wl,-rpath,$ORIGIN", "-pthread"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return exe

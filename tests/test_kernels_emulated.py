@@ -157,3 +157,27 @@ def test_regress_batch_items_of_different_sizes(emu, sd):
             single = emu_lib.regress(emu, mid, None, pyr1[i], pyr2[i], props[i])
             assert torch.equal(m[start:start + c], single["matches1"]) and torch.equal(p[start:start + c], single["probs1"])
         start += c
+
+
+@pytest.mark.parametrize("ksize", [2, 1])
+def test_plain_c_example_end_to_end(ksize, emu, ncn, sd, tmp_path):
+    """examples/cabi_coarse.c itself (argument order, buffer sizes, file format), compiled against the stand-in and
+    run on the CPU, against the ctypes calls into the same emulated library: bit-identical outputs.  On the GPU box
+    tests/test_plain_c_host.py runs the gcc-built program against the real library."""
+    import subprocess
+    import build_emu
+    import cabi_example_io as io
+    exe = build_emu.build_example()
+    pairs = [synthetic.make_correlated_pyramids(700 + i, 64, 96) for i in range(3)]
+    fa = torch.stack([p[0][4] for p in pairs]).contiguous()
+    fb = torch.stack([p[1][4] for p in pairs]).contiguous()
+    io.write_input(tmp_path / "in.bin", sd, fa, fb, ksize)
+    res = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    corr, delta = emu_lib.coarse_forward_batch(emu, ncn, fa, fb, ksize)
+    m, sc = emu_lib.coarse_matches_batch(emu, corr, delta, ksize, 8)
+    c_corr, c_delta, c_m, c_s = io.read_output(tmp_path / "out.bin", corr.numel(), sc.numel(), ksize)
+    assert np.array_equal(c_corr, corr.numpy().ravel())
+    if ksize > 1:
+        assert np.array_equal(c_delta, delta.numpy().ravel())
+    assert np.array_equal(c_m, m.numpy().ravel()) and np.array_equal(c_s, sc.numpy().ravel())

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 import torch
 
+import cabi_example_io as io
 import golden_util as gu
 from patch2pix_amd.utils import synthetic
 
@@ -42,26 +43,14 @@ def test_plain_c_host_matches_python_host(ksize, dev, ops, weights, tmp_path):
     pairs = [synthetic.make_correlated_pyramids(700 + i, H, W) for i in range(B)]
     fa = torch.stack([p[0][4] for p in pairs]).contiguous()
     fb = torch.stack([p[1][4] for p in pairs]).contiguous()
-    _, C, h, w = fa.shape
-    with open(tmp_path / "in.bin", "wb") as f:
-        f.write(np.array([B, C, h, w, h, w, ksize, 8], dtype=np.int32).tobytes())
-        for key in ("ncn.conv.0.weight", "ncn.conv.0.bias", "ncn.conv.2.weight", "ncn.conv.2.bias"):
-            f.write(sd[key].detach().cpu().numpy().astype(np.float32).tobytes())
-        f.write(fa.numpy().tobytes())
-        f.write(fb.numpy().tobytes())
+    io.write_input(tmp_path / "in.bin", sd, fa, fb, ksize)
     res = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
     corr, delta = ops.coarse_forward_batch(fa.to(dev), fb.to(dev), ksize, ncn)
     m, sc = ops.coarse_matches_batch(corr, delta, ksize, 8, True)
-    raw = open(tmp_path / "out.bin", "rb").read()
-    ncell, nmatch, off = corr.numel(), sc.numel(), 0
-    c_corr = np.frombuffer(raw, np.float32, ncell, off); off += 4 * ncell
+    c_corr, c_delta, c_m, c_s = io.read_output(tmp_path / "out.bin", corr.numel(), sc.numel(), ksize)
     np.testing.assert_allclose(c_corr, corr.cpu().numpy().ravel(), rtol=1e-6, atol=1e-9)
     if ksize > 1:
-        c_delta = np.frombuffer(raw, np.uint8, ncell, off); off += ncell
         assert np.array_equal(c_delta, delta.cpu().numpy().ravel())
-    c_m = np.frombuffer(raw, np.int64, nmatch * 4, off); off += 8 * nmatch * 4
     assert np.array_equal(c_m, m.cpu().numpy().ravel())
-    c_s = np.frombuffer(raw, np.float32, nmatch, off); off += 4 * nmatch
     np.testing.assert_allclose(c_s, sc.cpu().numpy().ravel(), rtol=1e-6)
-    assert off == len(raw)
