@@ -181,3 +181,30 @@ def test_plain_c_example_end_to_end(ksize, emu, ncn, sd, tmp_path):
     if ksize > 1:
         assert np.array_equal(c_delta, delta.numpy().ravel())
     assert np.array_equal(c_m, m.numpy().ravel()) and np.array_equal(c_s, sc.numpy().ravel())
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_coarse_stage_random_shapes(seed, emu, ncn, sd):
+    """Feature maps of unrelated, odd sizes for the two images (down to 1x1), any channel count the library accepts,
+    small batches: volume and relocalisation against the oracle, match extraction bit-exact on the kernel's volume."""
+    rng = np.random.RandomState(100 + seed)
+    ksize = int(rng.choice([1, 2]))
+    hA, wA, hB, wB = [int(rng.randint(1, 8)) * ksize for _ in range(4)]
+    C, B = int(rng.choice([32, 64, 128, 256])), int(rng.choice([1, 2, 3]))
+    g = torch.Generator().manual_seed(seed)
+    fa, fb = torch.randn(B, C, hA, wA, generator=g), torch.randn(B, C, hB, wB, generator=g)
+    corr, delta = emu_lib.coarse_forward_batch(emu, ncn, fa, fb, ksize)
+    m, s = emu_lib.coarse_matches_batch(emu, corr, delta, ksize, 8)
+    o_ncn, _, _ = orc.split_params(sd)
+    for b in range(B):
+        rc, rd = orc.coarse_forward(fa[b], fb[b], ksize, o_ncn)
+        np.testing.assert_allclose(corr[b].numpy(), rc.numpy(), rtol=3e-4, atol=1e-7)
+        kd = None
+        if ksize > 1:
+            k, d = ksize, delta[b].long()
+            ref_s = ((rd[0] * k + rd[1]) * k + rd[2]) * k + rd[3]
+            assert int((d != ref_s).sum()) <= 1, "relocalisation argmax differs beyond a near-tie"
+            kd = [d // (k * k * k), (d // (k * k)) % k, (d // k) % k, d % k]
+        rm, rs = orc.cal_coarse_matches(corr[b], kd, ksize, 8)
+        assert torch.equal(m[b], rm)
+        assert torch.allclose(s[b], rs, rtol=1e-4)
