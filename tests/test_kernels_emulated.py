@@ -196,9 +196,15 @@ def test_coarse_stage_random_shapes(seed, emu, ncn, sd):
     corr, delta = emu_lib.coarse_forward_batch(emu, ncn, fa, fb, ksize)
     m, s = emu_lib.coarse_matches_batch(emu, corr, delta, ksize, 8)
     o_ncn, _, _ = orc.split_params(sd)
+    o64, _, _ = orc.split_params(sd, torch.float64)
     for b in range(B):
         rc, rd = orc.coarse_forward(fa[b], fb[b], ksize, o_ncn)
-        np.testing.assert_allclose(corr[b].numpy(), rc.numpy(), rtol=3e-4, atol=1e-7)
+        # Unstructured features on tiny volumes can be ill-conditioned (the row/column maximum of the consensus output
+        # is a near-cancelling sum and enters the final mutual matching cubed): the yardstick is how far the fp32
+        # oracle itself is from an fp64 evaluation.
+        r64, _ = orc.coarse_forward(fa[b].double(), fb[b].double(), ksize, o64)
+        rel = lambda x: ((x.double() - r64).abs() / r64.abs().clamp_min(1e-30)).max().item()
+        assert rel(corr[b]) <= max(3e-4, 4 * rel(rc)), (rel(corr[b]), rel(rc))
         kd = None
         if ksize > 1:
             k, d = ksize, delta[b].long()
