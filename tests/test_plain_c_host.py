@@ -38,7 +38,7 @@ def test_plain_c_host_matches_python_host(ksize, dev, ops, weights, tmp_path):
     import subprocess
     from patch2pix_amd import build
     sd, ncn = weights
-    exe = build.build_examples(verbose=False)
+    exe = build.build_examples(verbose=False, trust_existing=True)
     H, W, B = 96, 128, 3
     pairs = [synthetic.make_correlated_pyramids(700 + i, H, W) for i in range(B)]
     fa = torch.stack([p[0][4] for p in pairs]).contiguous()
