@@ -130,10 +130,13 @@ int p2p_coarse_matches_batch(const float *corr4d, const uint8_t *delta, int batc
 /* ---- fine stage ------------------------------------------------------------------------------ */
 
 /* One image's feature pyramid levels feat_idx [0,1,2,3] (reference networks/resnet.py:138-157 with
- * change_stride): device pointers [3,H,W], [64,H/2,W/2], [64,H/4,W/4], [128,H/8,W/8].         */
+ * change_stride): device pointers [3,H,W], [64,H1,W1], [64,H2,W2], [128,H3,W3] with Hj = ceil(H / 2^j)
+ * (the extents the backbone's strided layers produce for ANY H, W -- refine_matches loads images without
+ * rounding their size, utils/datasets/preprocess.py:7-30); gathered indices are clamped to H // 2^j - 1 like
+ * networks/utils.py:22-23.                                                                     */
 typedef struct p2p_pyramid {
     const float *level[4];
-    int height, width;      /* of level 0 (the network input); multiples of 8 */
+    int height, width;      /* of level 0 (the network input); 8 <= H, W < 32768 */
 } p2p_pyramid;
 
 /* Patch2Pix.forward_fine_match for one batch item -- reference networks/patch2pix.py:157-218:

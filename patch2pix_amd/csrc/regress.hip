@@ -106,7 +106,8 @@ __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
                 const int Rr = (j == 0) ? 16 : (j == 1) ? 9 : (j == 2) ? 5 : 3;
                 const int Cc = (j == 0) ? 3 : (j == 3) ? 128 : 64;
                 const int off = (j == 0) ? TILE_L0 : (j == 1) ? TILE_L1 : (j == 2) ? TILE_L2 : TILE_L3;
-                const int Hj = Hh >> j, Wj = Ww >> j;
+                const int Hj = Hh >> j, Wj = Ww >> j;                 // index clamp: dim // ds (networks/utils.py:22-23)
+                    const int Ha = level_dim(Hh, j), Wa = level_dim(Ww, j);  // extent of the backbone's map
                 const int r0 = clampi(y0[img] >> j, 0, Hj - 1);
                 const int c0 = clampi(x0[img] >> j, 0, Wj - 1);
                 const float *src = I.pyr[img][j];
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
                     const int cc = rem - r * Rr;
                     const int sy = min(r0 + r, Hj - 1);
                     const int sx = min(c0 + cc, Wj - 1);
-                    t[off + e] = src[((size_t)c * Hj + sy) * Wj + sx];
+                    t[off + e] = src[((size_t)c * Ha + sy) * Wa + sx];
                 }
             }
         }
@@ -477,8 +478,8 @@ extern "C" int p2p_regress_batch(const p2p_regressor *reg1, const p2p_regressor 
     for (int i = 0; i < nitems; ++i) {
         const p2p_pyramid *im[2] = {im1 + i, im2 + i};
         for (int s = 0; s < 2; ++s) {
-            P2P_REQUIRE(im[s]->height > 0 && im[s]->width > 0 && im[s]->height % 8 == 0 && im[s]->width % 8 == 0,
-                        P2P_EINVAL, "p2p_regress: item %d image %d size %dx%d must be positive multiples of 8", i, s + 1,
+            P2P_REQUIRE(im[s]->height >= 8 && im[s]->width >= 8 && im[s]->height < 32768 && im[s]->width < 32768,
+                        P2P_EINVAL, "p2p_regress: item %d image %d size %dx%d must be within [8, 32767]", i, s + 1,
                         im[s]->height, im[s]->width);
             for (int j = 0; j < 4; ++j) P2P_REQUIRE(im[s]->level[j], P2P_EINVAL, "p2p_regress: null pyramid level");
         }

@@ -31,6 +31,10 @@ struct RegressArgs {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// extent of pyramid level j for an image extent `dim`: the backbone's strided convolutions / pooling round UP
+// (networks/resnet.py: 7x7 s2 p3, 3x3 s2 p1), while the gather clamps indices to dim // 2^j - 1 (networks/utils.py:22-23)
+__device__ __forceinline__ int level_dim(int dim, int j) { return (dim + (1 << j) - 1) >> j; }
+
 // cell index of patch row/col `p` (0..15) at pyramid level j, relative to the staged tile's origin:
 // clamp(floor((origin+p)/2^j), 0, dim/2^j - 1) - clamp(floor(origin/2^j), ...)   (networks/utils.py:22-23)
 __device__ __forceinline__ int patch_cell(int origin, int p, int j, int dim) {

@@ -198,7 +198,8 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
                     const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
                     const int Cc = (j == 3) ? 128 : 64;
                     const int nk = (j == 1) ? 11 : (j == 2) ? 4 : 3;
-                    const int Hj = Hh >> j, Wj = Ww >> j;
+                    const int Hj = Hh >> j, Wj = Ww >> j;                 // index clamp: dim // ds (networks/utils.py:22-23)
+                    const int Ha = level_dim(Hh, j), Wa = level_dim(Ww, j);  // extent of the backbone's map
                     const int r0 = clampi(Y0(img) >> j, 0, Hj - 1);
                     const int c0 = clampi(X0(img) >> j, 0, Wj - 1);
                     const float *src = I.pyr[img][j];
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
                         const int r = rem / Rr;
                         const int cc = rem - r * Rr;
                         const float v = (e < Cc * Rr * Rr)
-                                            ? src[((size_t)c * Hj + min(r0 + r, Hj - 1)) * Wj + min(c0 + cc, Wj - 1)] : 0.f;
+                                            ? src[((size_t)c * Ha + min(r0 + r, Hj - 1)) * Wa + min(c0 + cc, Wj - 1)] : 0.f;
                         if (j == 1) g1[img][k] = v; else if (j == 2) g2[img][k] = v; else g3[img][k] = v;
                     }
                 }

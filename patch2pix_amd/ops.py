@@ -198,7 +198,10 @@ def _pyramid(levels):
         raise ValueError("a pyramid is the 4 maps of feat_idx [0,1,2,3]")
     lv = [_f32c(t, "pyramid level") for t in levels]
     h, w = lv[0].shape[-2:]
-    exp = [(3, h, w), (64, h // 2, w // 2), (64, h // 4, w // 4), (128, h // 8, w // 8)]
+    if h < 8 or w < 8:
+        raise ValueError(f"images must be at least 8x8 pixels (got {h}x{w})")
+    up = lambda d, j: (d + (1 << j) - 1) >> j          # the backbone's strided layers round up (resnet.py)
+    exp = [(3, h, w), (64, up(h, 1), up(w, 1)), (64, up(h, 2), up(w, 2)), (128, up(h, 3), up(w, 3))]
     for t, e in zip(lv, exp):
         if tuple(t.shape) != e:
             raise ValueError(f"pyramid level has shape {tuple(t.shape)}, expected {e}")

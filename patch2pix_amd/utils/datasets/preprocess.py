@@ -1,5 +1,7 @@
 """Image loading for matching -- role of reference utils/datasets/preprocess.py:32-60,83-91.
 
+`load_im_tensor` (reference :7-30) is the loader of `refine_matches`: optional down-scaling to `imsize` with plain
+rounding (no multiple-of-16 constraint), a grey copy for third-party coarse matchers, batch axis, on the device.
 Host side (PIL) like the reference; the output feeds the backbone.  Target size = the original
 size scaled so that max(w,h) == imsize (never up-sampled) and rounded *down* to a multiple of
 upsample*k_size; bicubic resize; /255; ImageNet mean/std."""
@@ -9,6 +11,32 @@ from PIL import Image
 
 _MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(3, 1, 1)
 _STD = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(3, 1, 1)
+
+
+def _normalised(img):
+    arr = np.array(img, dtype=np.float32).transpose(2, 0, 1)
+    arr /= 255.0
+    return (torch.from_numpy(arr) - torch.from_numpy(_MEAN)) / torch.from_numpy(_STD)
+
+
+def load_im_tensor(im_path, device, imsize=None, with_gray=True):
+    """-> (im [1,3,H,W] normalised, gray [1,1,H,W] in [0,1], (wo/wt, ho/ht)) or (im, scale) without grey."""
+    im = Image.open(im_path)
+    wt, ht = wo, ho = im.width, im.height
+    if imsize and max(wo, ho) > imsize and imsize > 0:
+        s = imsize / max(wo, ho)
+        ht, wt = int(round(ho * s)), int(round(wo * s))
+        im = im.resize((wt, ht), Image.BICUBIC)
+    scale = (wo / wt, ho / ht)
+    gray = None
+    if with_gray:
+        g = np.array(im.convert("L"), dtype=np.float32) / 255.0
+        gray = torch.from_numpy(g)[None, None].to(device)
+    rgb = im if im.mode == "RGB" else im.convert("RGB")
+    t = _normalised(rgb).unsqueeze(0).to(device)
+    if with_gray:
+        return t, gray, scale
+    return t, scale
 
 
 def cal_rescale_size(image_size, w, h, k_size=2, scale_factor=1 / 16, no_print=True):
@@ -25,10 +53,7 @@ def load_im_flexible(im_path, k_size=2, upsample=16, imsize=None, crop_square=Fa
         imsize = max(wo, ho)
     wt, ht = cal_rescale_size(imsize, wo, ho, k_size=k_size, scale_factor=1.0 / upsample)
     img = img.resize((wt, ht), Image.BICUBIC)
-    arr = np.array(img, dtype=np.float32).transpose(2, 0, 1)
-    arr /= 255.0
-    t = torch.from_numpy(arr)
-    t = (t - torch.from_numpy(_MEAN)) / torch.from_numpy(_STD)
+    t = _normalised(img)
     if crop_square:
         t = t[:, :t.shape[2], :]
     return t, (wo / wt, ho / ht)

@@ -1,7 +1,8 @@
 """Entry points of the matching path with the reference's names and contracts.
 
 Role of reference utils/eval/model_helper.py: `load_model(ckpt_path, method, lprint)`,
-`estimate_matches(net, im1, im2, ksize, ncn_thres, mutual, io_thres, eval_type, imsize)` and the two matcher
+`estimate_matches(net, im1, im2, ksize, ncn_thres, mutual, io_thres, eval_type, imsize)`,
+`refine_matches(im1_path, im2_path, net, coarse_matcher, io_thres, imsize, coarse_only)` and the two matcher
 factories `init_patch2pix_matcher(args)` / `init_ncn_matcher(args)`.  Signatures, defaults and return layouts are the
 reference's (what image-matching-toolbox binds to); the bodies are organised around the HIP library underneath.
 
@@ -17,7 +18,7 @@ import numpy as np
 import torch
 
 from ..common.setup_helper import load_weights
-from ..datasets.preprocess import load_im_flexible
+from ..datasets.preprocess import load_im_flexible, load_im_tensor
 from ...networks.patch2pix import Patch2Pix
 
 _SILENT = lambda *a, **k: None
@@ -121,3 +122,17 @@ def estimate_matches(net, im1, im2, ksize=2, ncn_thres=0.0, mutual=True, io_thre
     if confident.size:
         refined, confidence, proposals = refined[confident], confidence[confident], proposals[confident]
     return to_original * refined, confidence, to_original * proposals
+
+
+def refine_matches(im1_path, im2_path, net, coarse_matcher, io_thres=0.0, imsize=None, coarse_only=False):
+    """Refine the matches of a third-party coarse matcher (reference :111-127): `coarse_matcher(grey1, grey2)` gets
+    the two grey images [1,1,H,W] and returns [N,4] pixel matches in the loaded images' frame."""
+    im1, grey1, sc1 = load_im_tensor(im1_path, net.device, imsize, with_gray=True)
+    im2, grey2, sc2 = load_im_tensor(im2_path, net.device, imsize, with_gray=True)
+    to_original = np.array([sc1 + sc2])
+    coarse = coarse_matcher(grey1, grey2)
+    if coarse_only:
+        return to_original * coarse.cpu().data.numpy(), None, None
+    with torch.no_grad():
+        refined, scores, coarse = net.refine_matches(im1, im2, coarse, io_thres)
+    return to_original * refined, scores, to_original * coarse
