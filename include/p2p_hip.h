@@ -69,16 +69,21 @@ typedef struct p2p_regressor_params {
 int p2p_regressor_create(const p2p_regressor_params *params, p2p_regressor **out);
 void p2p_regressor_destroy(p2p_regressor *reg);
 
-/* Arithmetic used for the two convolutions of a regressor (everything else is fp32 either way):
+/* Arithmetic used for the two convolutions of a regressor (everything else is fp32 either way; the
+ * reference computes them in fp32, networks/modules.py:76-87):
  *   P2P_REGRESS_F32    v_mfma_f32_32x32x2_f32, bit-identical to an fp32 fma chain;
- *   P2P_REGRESS_BF16X2 every fp32 operand split into two bf16 (16 significant bits), three
- *                      v_mfma_f32_32x32x16_bf16 per product, fp32 accumulation: 5.3x the matrix-core
- *                      rate, regressed coordinates within ~2e-4 px of the fp32 evaluation.
- * New handles start in the mode named by the environment variable P2P_REGRESS_MODE ("f32" |
+ *   P2P_REGRESS_BF16X3 fp32-equivalent on the bf16 matrix cores: every fp32 operand is the exact sum of three
+ *                      bf16 numbers (24 significant bits), six v_mfma_f32_32x32x16_bf16 per product (all terms
+ *                      down to 2^-16 of the product; the rest is below fp32 round-off), fp32 accumulation.
+ *                      As accurate as P2P_REGRESS_F32 against an fp64 evaluation, ceiling 2.65x higher;
+ *   P2P_REGRESS_BF16X2 reduced precision, opt-in only: two bf16 per operand (16 significant bits), three
+ *                      products; regressed coordinates within ~2.5e-4 px of an fp64 evaluation.
+ * New handles start in the mode named by the environment variable P2P_REGRESS_MODE ("f32" | "bf16x3" |
  * "bf16x2"), else P2P_REGRESS_DEFAULT.                                                          */
 #define P2P_REGRESS_F32     0
 #define P2P_REGRESS_BF16X2  1
-#define P2P_REGRESS_DEFAULT P2P_REGRESS_BF16X2
+#define P2P_REGRESS_BF16X3  2
+#define P2P_REGRESS_DEFAULT P2P_REGRESS_BF16X3
 int p2p_regressor_set_mode(p2p_regressor *reg, int mode);
 int p2p_regressor_get_mode(const p2p_regressor *reg);
 

@@ -116,6 +116,55 @@ def case_estimate_matches(ref, name, seed, H, W, imsize):
           "coarse", res["coarse_matches"].shape)
 
 
+def case_full_size(ref, net, name, seed, H, W, ptmax):
+    """BASELINE configuration (480x640, ksize 2, ptmax 400) through the unmodified reference: all coarse rows, the
+    ptmax-sampled proposals (training-time option of networks/utils.py:55-63, global numpy RNG seeded with 0) and both
+    regressors on them.  The 1.44 M-cell volume itself is not stored: a strided sample of corr4d and the histogram
+    of the relocalisation codes stand in for it (the rows pin every argmax that is consumed)."""
+    p1, p2 = synthetic.make_correlated_pyramids(seed, H, W)
+    f1 = [t[None] for t in p1]
+    f2 = [t[None] for t in p2]
+    with torch.no_grad():
+        corr, delta = net.forward_coarse_match(p1[4][None], p2[4][None], ksize=2)
+        m, s = net.cal_coarse_matches(corr, delta, ksize=2, upsample=8, center=True)
+        fm, fs = ref.utils.filter_coarse(m, s, 0.0, True)
+        np.random.seed(0)
+        cm, cs = ref.utils.filter_coarse(m, s, 0.0, True, ptmax=ptmax)
+        mid, midp = net.forward_fine_match(f1, f2, cm, 16, "center", net.regress_mid)
+        fine, finep = net.forward_fine_match(f1, f2, mid, 16, "center", net.regress_fine)
+    code = ((delta[0] * 2 + delta[1]) * 2 + delta[2]) * 2 + delta[3]
+    flat = corr[0, 0].reshape(-1)
+    np.savez_compressed(os.path.join(GOLDEN, name), seed=seed, H=H, W=W, ptmax=ptmax, sd_seed=SD_SEED,
+                        input_checksum=checksum(p1 + p2), all_matches=np_(m[0]).astype(np.int16), all_scores=np_(s[0]),
+                        mutual_matches=np_(fm[0]).astype(np.int16), corr_sample_stride=997,
+                        corr_sample=np_(flat[::997]), delta_hist=np.bincount(np_(code).reshape(-1), minlength=16),
+                        proposals=np_(cm[0]).astype(np.int16), proposal_scores=np_(cs[0]),
+                        mid=np_(mid[0]), mid_scores=np_(midp[0]), fine=np_(fine[0]), fine_scores=np_(finep[0]))
+    print(name, "rows", m.shape[1], "mutual", fm[0].shape[0], "proposals", cm[0].shape[0])
+
+
+def case_real_pair(ref, name, pair_dir, imsize):
+    """The reference's estimate_matches (utils/eval/model_helper.py:64-109) on a real image pair of its examples/
+    directory (copied to tests/golden/images), synthetic checkpoint in the reference's own schema."""
+    ckpt = synthetic.make_checkpoint(SD_SEED)
+    im1, im2 = os.path.join(GOLDEN, "images", pair_dir, "1.jpg"), os.path.join(GOLDEN, "images", pair_dir, "2.jpg")
+    with tempfile.TemporaryDirectory() as td:
+        torch.save(ckpt, os.path.join(td, "ckpt.pth"))
+        net = ref.model_helper.load_model(os.path.join(td, "ckpt.pth"), method="patch2pix", lprint=lambda *a: None)
+        res = {}
+        for tag, kw in (("fine", dict(eval_type="fine", io_thres=0.25)), ("coarse", dict(eval_type="coarse", ncn_thres=0.0))):
+            m, s, c = ref.model_helper.estimate_matches(net, im1, im2, ksize=2, imsize=imsize, **kw)
+            res[tag + "_matches"], res[tag + "_scores"], res[tag + "_coarse"] = m, s, c
+        # the layer-3 features the reference's backbone produced on this CPU: lets a test tell backbone drift
+        # (another CPU / MIOpen) from a difference in the matching path
+        t1, _ = ref.model_helper.load_im_flexible(im1, 2, net.upsample, imsize=imsize)
+        with torch.no_grad():
+            feat = net.extract(t1[None], early_feat=True)
+    np.savez_compressed(os.path.join(GOLDEN, name), pair=pair_dir, imsize=(-1 if imsize is None else imsize), sd_seed=SD_SEED,
+                        feat1_checksum=checksum([feat]), feat1_shape=np.array(feat.shape), **res)
+    print(name, "fine", res["fine_matches"].shape, "coarse", res["coarse_matches"].shape, "feat", tuple(feat.shape))
+
+
 SD_SEED = 0
 
 
@@ -140,7 +189,21 @@ def main():
         pass
     case_estimate_matches(ref, "estimate_matches_240x320", 51, 240, 320, None)
     case_estimate_matches(ref, "estimate_matches_imsize256", 52, 300, 400, 256)
+    new_cases(ref, net)
+
+
+def new_cases(ref, net):
+    """Round-2 fixtures (kept separate so that `python -m oracle.make_golden --new` leaves the older files alone)."""
+    case_full_size(ref, net, "full_480x640", 77, 480, 640, 400)
+    case_real_pair(ref, "real_pair_1", "pair_1", None)
+    case_real_pair(ref, "real_pair_2", "pair_2", 640)
+    case_real_pair(ref, "real_pair_3", "pair_3", 1024)
 
 
 if __name__ == "__main__":
-    main()
+    if "--new" in sys.argv:
+        os.makedirs(GOLDEN, exist_ok=True)
+        _sd = synthetic.make_state_dict(SD_SEED)
+        new_cases(load_reference(), build_reference_net(_sd, synthetic.default_regressor_config()))
+    else:
+        main()

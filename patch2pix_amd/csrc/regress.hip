@@ -343,18 +343,19 @@ static void fold_bn(const p2p_bn_params &bn, int n, float *scale, float *shift) 
 
 using namespace p2p;
 
-// Arithmetic of the two convolutions: the environment variable P2P_REGRESS_MODE ("f32" | "bf16x2")
+// Arithmetic of the two convolutions: the environment variable P2P_REGRESS_MODE ("f32" | "bf16x3" | "bf16x2")
 // picks the default for newly created regressors; p2p_regressor_set_mode overrides it per handle.
 static int default_regress_mode() {
     const char *e = std::getenv("P2P_REGRESS_MODE");
     if (e && std::strcmp(e, "f32") == 0) return P2P_REGRESS_F32;
     if (e && std::strcmp(e, "bf16x2") == 0) return P2P_REGRESS_BF16X2;
+    if (e && std::strcmp(e, "bf16x3") == 0) return P2P_REGRESS_BF16X3;
     return P2P_REGRESS_DEFAULT;
 }
 
 extern "C" int p2p_regressor_set_mode(p2p_regressor *reg, int mode) {
     P2P_REQUIRE(reg, P2P_EINVAL, "p2p_regressor_set_mode: null handle");
-    P2P_REQUIRE(mode == P2P_REGRESS_F32 || mode == P2P_REGRESS_BF16X2, P2P_EINVAL, "p2p_regressor_set_mode: unknown mode %d", mode);
+    P2P_REQUIRE(mode == P2P_REGRESS_F32 || mode == P2P_REGRESS_BF16X2 || mode == P2P_REGRESS_BF16X3, P2P_EINVAL, "p2p_regressor_set_mode: unknown mode %d", mode);
     reg->mode = mode;
     return P2P_OK;
 }
@@ -375,6 +376,7 @@ extern "C" int p2p_regressor_create(const p2p_regressor_params *p, p2p_regressor
     auto take = [&](size_t n) { size_t o = off; off += (n + 63) & ~size_t(63); return o; };
     const size_t o_wp1 = take(WP1_FLOATS), o_wp2 = take(WP2_FLOATS);
     const size_t o_ws1 = take(WS1_FLOATS), o_ws2 = take(WS2_FLOATS);
+    const size_t o_wx1 = take(WX1_FLOATS), o_wx2 = take(WX2_FLOATS);
     const size_t o_bn1s = take(512), o_bn1b = take(512), o_bn2s = take(512), o_bn2b = take(512);
     const size_t o_fc1t = take(512 * 512), o_fc1b = take(512), o_bnf1s = take(512), o_bnf1b = take(512);
     const size_t o_fc2t = take(256 * 512), o_fc2b = take(256), o_bnf2s = take(256), o_bnf2b = take(256);
@@ -409,6 +411,7 @@ extern "C" int p2p_regressor_create(const p2p_regressor_params *p, p2p_regressor
                     }
         }
     pack_split_weights(p->conv1_w, p->conv2_w, &h[o_ws1], &h[o_ws2]);
+    pack_x3_weights(p->conv1_w, p->conv2_w, &h[o_wx1], &h[o_wx2]);
     fold_bn(p->bn1, 512, &h[o_bn1s], &h[o_bn1b]);
     fold_bn(p->bn2, 512, &h[o_bn2s], &h[o_bn2b]);
     fold_bn(p->bnf1, 512, &h[o_bnf1s], &h[o_bnf1b]);
@@ -435,6 +438,7 @@ extern "C" int p2p_regressor_create(const p2p_regressor_params *p, p2p_regressor
     r->dev = dev;
     r->wp1 = dev + o_wp1; r->wp2 = dev + o_wp2;
     r->ws1 = dev + o_ws1; r->ws2 = dev + o_ws2;
+    r->wx1 = dev + o_wx1; r->wx2 = dev + o_wx2;
     r->mode = default_regress_mode();
     r->bn1s = dev + o_bn1s; r->bn1b = dev + o_bn1b; r->bn2s = dev + o_bn2s; r->bn2b = dev + o_bn2b;
     r->fc1t = dev + o_fc1t; r->fc1b = dev + o_fc1b; r->bnf1s = dev + o_bnf1s; r->bnf1b = dev + o_bnf1b;
@@ -452,7 +456,7 @@ extern "C" void p2p_regressor_destroy(p2p_regressor *reg) {
 
 static RegDev to_dev(const p2p_regressor *r) {
     RegDev d;
-    d.wp1 = r->wp1; d.wp2 = r->wp2; d.ws1 = r->ws1; d.ws2 = r->ws2; d.bn1s = r->bn1s; d.bn1b = r->bn1b; d.bn2s = r->bn2s; d.bn2b = r->bn2b;
+    d.wp1 = r->wp1; d.wp2 = r->wp2; d.ws1 = r->ws1; d.ws2 = r->ws2; d.wx1 = r->wx1; d.wx2 = r->wx2; d.bn1s = r->bn1s; d.bn1b = r->bn1b; d.bn2s = r->bn2s; d.bn2b = r->bn2b;
     d.fc1t = r->fc1t; d.fc1b = r->fc1b; d.bnf1s = r->bnf1s; d.bnf1b = r->bnf1b;
     d.fc2t = r->fc2t; d.fc2b = r->fc2b; d.bnf2s = r->bnf2s; d.bnf2b = r->bnf2b; d.fc3 = r->fc3; d.fc3b = r->fc3b;
     return d;
@@ -521,7 +525,9 @@ extern "C" int p2p_regress_batch(const p2p_regressor *reg1, const p2p_regressor 
         a.matches[1] = adv(matches2, 4); a.probs[1] = adv(probs2, 1); a.raw[1] = adv(raw2, 5);
         if (n > 0) {
             int st;
-            if (reg1->mode == P2P_REGRESS_BF16X2) {
+            if (reg1->mode == P2P_REGRESS_BF16X3) {
+                st = launch_regress_x3(a, n, (hipStream_t)stream);
+            } else if (reg1->mode == P2P_REGRESS_BF16X2) {
                 st = launch_regress_split(a, n, (hipStream_t)stream);
             } else {
                 hipLaunchKernelGGL(regress_kernel, dim3(n), dim3(NT), LDS_BYTES, (hipStream_t)stream, a);

@@ -1,6 +1,7 @@
 // Pieces shared by the two fine-stage kernels (exact-f32 MFMA and split-bf16 MFMA).
 #pragma once
 #include "p2p_common.h"
+#include <cstring>
 
 namespace p2p {
 
@@ -10,6 +11,7 @@ constexpr int MAXB = 16;                // image pairs per launch
 struct RegDev {
     const float *wp1, *wp2;             // f32 MFMA-fragment order (regress.hip)
     const float *ws1, *ws2;             // split-bf16 fragment order (regress_split.hip), viewed as 16-byte units
+    const float *wx1, *wx2;             // three-plane bf16 fragment order (regress_x3.hip)
     const float *bn1s, *bn1b, *bn2s, *bn2b;
     const float *fc1t, *fc1b, *bnf1s, *bnf1b, *fc2t, *fc2b, *bnf2s, *bnf2b, *fc3, *fc3b;
 };
@@ -136,5 +138,27 @@ constexpr int S2_UNITS = 2 * S2_SLABS;   // conv2 likewise: [tap][n-tile][32 sla
 constexpr size_t WS2_FLOATS = (size_t)8 * (S2_UNITS + SPF) * 512;
 void pack_split_weights(const float *conv1_w, const float *conv2_w, float *ws1, float *ws2);   // host
 int launch_regress_split(const RegressArgs &a, int n, hipStream_t stream);
+void split_conv1_index(int slab, int half, int j, int &ch, int &tap);   // K layout of conv1 shared by the bf16 kernels
+
+// regress_x3.hip: unit = (slab of 16 K, n-tile), three bf16 planes = 3 KiB per (wave, unit); stream order [slab][n-tile]
+constexpr int XPF = 4;                   // units the weight prefetch may run past the end of a stream
+constexpr size_t WX1_FLOATS = (size_t)8 * (S1_UNITS + XPF) * 768;
+constexpr size_t WX2_FLOATS = (size_t)8 * (S2_UNITS + XPF) * 768;
+void pack_x3_weights(const float *conv1_w, const float *conv2_w, float *wx1, float *wx2);      // host
+int launch_regress_x3(const RegressArgs &a, int n, hipStream_t stream);
+
+// host-side bf16 helpers (round to nearest even)
+static inline uint16_t bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
 
 }  // namespace p2p

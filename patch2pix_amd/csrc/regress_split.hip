@@ -483,23 +483,10 @@ __global__ __launch_bounds__(NT, 2) void regress_split_kernel(RegressArgs args) 
 // --------------------------------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------------------------------
-static uint16_t bf16_rne(float f) {
-    uint32_t u;
-    std::memcpy(&u, &f, 4);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-static float bf16_to_f(uint16_t b) {
-    uint32_t u = (uint32_t)b << 16;
-    float f;
-    std::memcpy(&f, &u, 4);
-    return f;
-}
-
 // conv1 K layout (see the kernel): slabs 0-3 hold level 0 of both images with K = img*32 + tap*3 + c;
 // slab 4 + (tap*2 + img)*16 + s holds 16 channels of level 1 (s 0-3), 2 (s 4-7) or 3 (s 8-15) of image `img`.
 // Returns the channel (0..517) of the concatenated regressor input and the tap, or ch = -1 for padding.
-static void split_conv1_index(int slab, int half, int j, int &ch, int &tap) {
+void split_conv1_index(int slab, int half, int j, int &ch, int &tap) {
     if (slab < 4) {
         const int kk = slab * 16 + 8 * half + j, img = kk >> 5, r = kk & 31;
         if (r >= 27) { ch = -1; tap = 0; return; }

@@ -17,7 +17,8 @@ def gather_matches(rows, pair_ids, group=None):
     rows:     [M, C] float tensor (e.g. C = 9: fine x1,y1,x2,y2, score, coarse x1,y1,x2,y2)
     pair_ids: [M] int64 tensor, the pair each row belongs to
     Returns (rows_all [sum M, C], pair_ids_all [sum M]) ordered by rank then local order, on every rank.
-    Two collectives: counts (int64 [1] per rank), then one padded payload all_gather.
+    Three small collectives: counts (int64 [1] per rank), then one padded all_gather of the float payload and one of
+    the int64 pair ids (ids travel as integers, never through a float).
     """
     if not (dist.is_available() and dist.is_initialized()):
         return rows, pair_ids
@@ -29,10 +30,13 @@ def gather_matches(rows, pair_ids, group=None):
     counts = [int(c.item()) for c in counts]
     cap = max(max(counts), 1)
     c = rows.shape[1]
-    payload = torch.zeros((cap, c + 1), dtype=torch.float64 if rows.dtype == torch.float64 else torch.float32, device=dev)
-    payload[:rows.shape[0], :c] = rows
-    payload[:rows.shape[0], c] = pair_ids.to(payload.dtype)      # exact for ids < 2^24
+    payload = torch.zeros((cap, c), dtype=rows.dtype, device=dev)
+    payload[:rows.shape[0]] = rows
+    ids = torch.zeros((cap,), dtype=torch.int64, device=dev)
+    ids[:rows.shape[0]] = pair_ids.to(torch.int64)
     gathered = [torch.empty_like(payload) for _ in range(world)]
+    gathered_ids = [torch.empty_like(ids) for _ in range(world)]
     dist.all_gather(gathered, payload, group=group)
-    out = torch.cat([g[:n] for g, n in zip(gathered, counts)])
-    return out[:, :c].to(rows.dtype), out[:, c].round().to(torch.int64)
+    dist.all_gather(gathered_ids, ids, group=group)
+    return (torch.cat([g[:n] for g, n in zip(gathered, counts)]),
+            torch.cat([g[:n] for g, n in zip(gathered_ids, counts)]))

@@ -15,6 +15,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
+BIG = (1 << 40) + 1                            # pair ids beyond float precision must survive the gather
+
+
 def _fake_rows(pair_id):
     n = (pair_id * 7) % 5                      # ragged, includes empty results
     g = torch.Generator().manual_seed(pair_id)
@@ -26,7 +29,7 @@ def _worker(rank, world, port, num_pairs, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     mine = shard_pairs(num_pairs, rank, world)
     rows = [_fake_rows(p) for p in mine]
-    ids = [torch.full((r.shape[0],), p, dtype=torch.int64) for r, p in zip(rows, mine)]
+    ids = [torch.full((r.shape[0],), p + BIG, dtype=torch.int64) for r, p in zip(rows, mine)]
     rows_all, ids_all = gather_matches(torch.cat(rows) if rows else torch.zeros(0, 9),
                                        torch.cat(ids) if ids else torch.zeros(0, dtype=torch.int64))
     ret[rank] = (rows_all, ids_all)
@@ -50,8 +53,8 @@ def test_two_rank_gather_of_ragged_matches():
     r1, i1 = ret[1]
     assert torch.equal(r0, r1) and torch.equal(i0, i1)          # every rank holds the same gathered set
     for p in range(num_pairs):                                   # and it is exactly the union of the shards
-        assert torch.equal(r0[i0 == p], _fake_rows(p))
-    assert r0.shape[0] == sum((p * 7) % 5 for p in range(num_pairs))
+        assert torch.equal(r0[i0 == p + BIG], _fake_rows(p))
+    assert r0.shape[0] == sum((p * 7) % 5 for p in range(num_pairs)) and i0.dtype == torch.int64
 
 
 def test_single_process_is_identity():

@@ -84,7 +84,7 @@ def test_coarse_batch_equals_single_pairs(emu, ncn):
             assert torch.equal(m[i], m1[0]) and torch.equal(s[i], s1[0])
 
 
-@pytest.mark.parametrize("mode", ["bf16x2", "f32"])
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x2", "f32"])
 def test_regressors_against_reference_golden(mode, emu, sd):
     """Both regressor kernels (split-bf16 and exact fp32 MFMA) on the first proposals of the reference's
     forward_fine_match golden: integer proposals through the mid regressor, float proposals through the fine one."""
@@ -214,3 +214,26 @@ def test_coarse_stage_random_shapes(seed, emu, ncn, sd):
         rm, rs = orc.cal_coarse_matches(corr[b], kd, ksize, 8)
         assert torch.equal(m[b], rm)
         assert torch.allclose(s[b], rs, rtol=1e-4)
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_regressor_on_image_sizes_that_are_not_multiples_of_8(mode, emu, sd):
+    """refine_matches loads images without rounding their size (utils/datasets/preprocess.py:7-30): the backbone's maps
+    then have ceil(H / 2^j) rows, while the gather clamps to H // 2^j - 1 (networks/utils.py:22-23) -- the last row /
+    column of an odd-sized map is never read.  Oracle = the reference's indexing on the same maps."""
+    H, W = 27, 37
+    gen = torch.Generator().manual_seed(3)
+    up = lambda d, j: (d + (1 << j) - 1) >> j
+
+    def pyr():
+        return [torch.randn(3, H, W, generator=gen)] + [torch.relu(torch.randn(c, up(H, j), up(W, j), generator=gen) + 0.3)
+                                                        for c, j in ((64, 1), (64, 2), (128, 3))]
+    p1, p2 = pyr(), pyr()
+    props = torch.tensor([[W, H, 0, 0], [W - 1, H - 1, 3, 5], [18, 13, 30, 20], [0, H, W, 0]])
+    _, mid_p, _ = orc.split_params(sd)
+    ref_mid, ref_p, ref_raw = orc.fine_level(p1, p2, props, mid_p)
+    sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+    out = emu_lib.regress(emu, emu_lib.regressor_create(emu, sub("regress_mid."), mode), None, p1, p2, props)
+    assert (out["raw1"] - ref_raw).abs().max() < 5e-5
+    assert (out["matches1"] - ref_mid).abs().max() <= COORD_TOL
+    assert (out["probs1"] - ref_p).abs().max() <= SCORE_TOL

@@ -1,20 +1,27 @@
 #!/bin/bash
 # Collect the round's evidence on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh TAG      -> gpurun_out/TAG_{bench.json,kernel_stats.txt,pmc.txt,traffic.json}
-# rocprofv3 is run from /tmp (its scratch files), counters in their own passes with --kernel-trace only, every pass
-# under its own timeout (a counter pass once ate a whole round's GPU budget).
+#   bash tools/collect_profiles.sh TAG [MODE ...]   -> gpurun_out/TAG_<mode>_{kernel_stats.txt,pmc.txt}, gpurun_out/regress_traffic.json
+# rocprofv3 is run from /tmp (its scratch files), counters in their own passes with --kernel-trace only (FETCH_SIZE
+# and WRITE_SIZE do not fit one pass: 3 + 2 of 4 TCC slots), every pass under its own timeout (a counter pass once ate
+# a whole round's GPU budget).  Copy what you want judged into profiles/.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
+shift || true
+MODES=${@:-bf16x3}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python $ROOT/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-tail -c 600 $OUT/${TAG}_bench.json
-timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_k -o bench -- python $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-python $ROOT/tools/prof_summary.py $(find /tmp/prof_k -name "*.db" | head -1) > $OUT/${TAG}_kernel_stats.txt
-head -12 $OUT/${TAG}_kernel_stats.txt
-timeout 300 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE --kernel-trace -d /tmp/prof_p1 -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY --kernel-trace -d /tmp/prof_p2 -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-python $ROOT/tools/pmc_summary.py $OUT/${TAG}_pmc.txt $OUT/${TAG}_traffic.json $(find /tmp/prof_p1 /tmp/prof_p2 -name "*.db")
-cat $OUT/${TAG}_traffic.json
+[ -f $ROOT/profiles/regress_traffic.json ] && cp $ROOT/profiles/regress_traffic.json $OUT/regress_traffic.json
+B="--no-cpu-baseline --no-parity --no-other-modes --no-e2e"
+for MODE in $MODES; do
+  rm -rf /tmp/prof_k /tmp/prof_p1 /tmp/prof_p2 /tmp/prof_p3
+  timeout 240 rocprofv3 --kernel-trace --stats -d /tmp/prof_k -o bench -- python $ROOT/bench.py --mode $MODE --steps 8 --warmup 2 $B > $OUT/${TAG}_${MODE}_profiled_bench.json 2>/dev/null
+  python $ROOT/tools/prof_summary.py $(find /tmp/prof_k -name "*.db" | head -1) > $OUT/${TAG}_${MODE}_kernel_stats.txt
+  head -8 $OUT/${TAG}_${MODE}_kernel_stats.txt
+  timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_p1 -o bench -- python $ROOT/bench.py --mode $MODE --steps 3 --warmup 1 $B > /dev/null 2>&1
+  timeout 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/prof_p3 -o bench -- python $ROOT/bench.py --mode $MODE --steps 3 --warmup 1 $B > /dev/null 2>&1
+  timeout 240 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY --kernel-trace -d /tmp/prof_p2 -o bench -- python $ROOT/bench.py --mode $MODE --steps 3 --warmup 1 $B > /dev/null 2>&1
+  python $ROOT/tools/pmc_summary.py $OUT/${TAG}_${MODE}_pmc.txt $OUT/regress_traffic.json $MODE $(find /tmp/prof_p1 /tmp/prof_p2 /tmp/prof_p3 -name "*.db")
+done
+cat $OUT/regress_traffic.json

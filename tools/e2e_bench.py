@@ -1,45 +1,68 @@
-"""End-to-end estimate_matches throughput (image files -> match arrays), informational:
-PIL load + resize, backbone on PyTorch-ROCm, HIP matching path, D2H."""
-import os, sys, time, tempfile
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-import torch
-from PIL import Image
-from patch2pix_amd.utils import synthetic
-from patch2pix_amd.utils.eval import model_helper
+"""End-to-end estimate_matches throughput (image files -> match arrays), informational (SURVEY 8d(ii)):
+PIL load + resize, backbone on PyTorch-ROCm (MIOpen), HIP matching path, D2H.  `measure()` is what bench.py
+reports under "e2e"; run as a script it prints the same dict."""
+import os
+import sys
+import tempfile
+import time
 
-torch.backends.cudnn.benchmark = True
-net = model_helper.load_model(synthetic.make_checkpoint(0), lprint=lambda *a: None)
-with tempfile.TemporaryDirectory() as td:
-    paths = []
-    for i in range(4):
-        a, b = synthetic.make_image_pair(100 + i, 480, 640)
-        pa, pb = os.path.join(td, f"{i}a.png"), os.path.join(td, f"{i}b.png")
-        Image.fromarray(a).save(pa); Image.fromarray(b).save(pb); paths.append((pa, pb))
-    for pa, pb in paths: model_helper.estimate_matches(net, pa, pb, ksize=2, io_thres=0.25)
-    torch.cuda.synchronize(); t0 = time.perf_counter(); n = 0
-    for rep in range(5):
-        for pa, pb in paths:
-            m, s, c = model_helper.estimate_matches(net, pa, pb, ksize=2, io_thres=0.25); n += 1
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"end-to-end estimate_matches: {n/dt:.1f} pairs/s ({dt/n*1e3:.1f} ms/pair), {m.shape[0]} matches in the last pair")
-    # streaming form: threaded loading, batched backbone, shared fine launch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch  # noqa: E402
+from PIL import Image  # noqa: E402
+
+from patch2pix_amd.utils import synthetic  # noqa: E402
+from patch2pix_amd.utils.eval import model_helper  # noqa: E402
+
+
+def measure(net, H=480, W=640, pairs=4, reps=3, stream_pairs=32):
+    """-> {per_pair_pairs_per_s, stream_pairs_per_s, backbone_ms_per_image, ...}; jpeg inputs (quality 95)."""
     from patch2pix_amd.utils.eval.stream import estimate_matches_stream
-    for ext, q in (("jpg", {"quality": 95}), ("png", {})):
-        files = []
-        for i in range(8):
-            a, b = synthetic.make_image_pair(200 + i, 480, 640)
-            pa, pb = os.path.join(td, f"s{i}a.{ext}"), os.path.join(td, f"s{i}b.{ext}")
-            Image.fromarray(a).save(pa, **q); Image.fromarray(b).save(pb, **q); files.append((pa, pb))
-        work = files * 8
-        list(estimate_matches_stream(net, files, batch=8, workers=16))
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+    out = {"input": f"{H}x{W} JPEG files, estimate_matches(ksize=2, io_thres=0.25); random-init weights, so the number of "
+                    "proposals per pair is the model's own mutual matches, not ptmax"}
+    with tempfile.TemporaryDirectory() as td:
+        paths = []
+        for i in range(max(pairs, 8)):
+            a, b = synthetic.make_image_pair(100 + i, H, W)
+            pa, pb = os.path.join(td, f"{i}a.jpg"), os.path.join(td, f"{i}b.jpg")
+            Image.fromarray(a).save(pa, quality=95)
+            Image.fromarray(b).save(pb, quality=95)
+            paths.append((pa, pb))
+        for pa, pb in paths[:2]:
+            model_helper.estimate_matches(net, pa, pb, ksize=2, io_thres=0.25)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        for _ in range(reps):
+            for pa, pb in paths[:pairs]:
+                m, s, c = model_helper.estimate_matches(net, pa, pb, ksize=2, io_thres=0.25)
+                n += 1
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["per_pair_pairs_per_s"] = n / dt
+        out["per_pair_matches_last"] = int(m.shape[0])
+        # streaming form: threaded loading, batched backbone, shared fine launch
+        work = (paths[:8] * (stream_pairs // 8 + 1))[:stream_pairs]
+        list(estimate_matches_stream(net, paths[:8], batch=8, workers=16))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         nres = sum(1 for _ in estimate_matches_stream(net, work, batch=8, workers=16))
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print(f"end-to-end estimate_matches_stream ({ext}): {nres/dt:.1f} pairs/s ({dt/nres*1e3:.1f} ms/pair)")
-    # backbone only
-    im = torch.randn(1, 3, 480, 640, device="cuda")
+        torch.cuda.synchronize()
+        out["stream_pairs_per_s"] = nres / (time.perf_counter() - t0)
+        out["stream"] = "estimate_matches_stream(batch=8, workers=16)"
+    im = torch.randn(2, 3, H, W, device=net.device)
     with torch.no_grad():
-        for _ in range(3): net.extract.pyramid(im)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(20): net.extract.pyramid(im)
-        torch.cuda.synchronize(); print(f"backbone forward_all: {(time.perf_counter()-t0)/20*1e3:.2f} ms per image")
+        for _ in range(3):
+            net.extract.pyramid(im)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            net.extract.pyramid(im)
+        torch.cuda.synchronize()
+        out["backbone_ms_per_image"] = (time.perf_counter() - t0) / 20 * 1e3
+    return out
+
+
+if __name__ == "__main__":
+    import json
+    torch.backends.cudnn.benchmark = True
+    print(json.dumps(measure(model_helper.load_model(synthetic.make_checkpoint(0), lprint=lambda *a: None)), indent=1))

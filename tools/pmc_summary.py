@@ -1,13 +1,15 @@
 #!/usr/bin/env python
 """Summarise rocprofv3 --pmc result databases (one per counter group) into text + the regress traffic json.
-usage: python tools/pmc_summary.py OUT_TXT OUT_JSON db1 db2 ..."""
+usage: python tools/pmc_summary.py OUT_TXT OUT_JSON MODE db1 db2 ...
+OUT_JSON is keyed by regressor mode ({"bf16x3": {...}, "f32": {...}}); an existing file is updated.  Every record carries
+the hash of the kernel sources it was measured with; bench.py reports `roofline.traffic` only when it matches."""
 import json
 import os
 import sqlite3
 import sys
 
 
-def main(out_txt, out_json, dbs):
+def main(out_txt, out_json, mode, dbs):
     rows = {}
     for path in dbs:
         c = sqlite3.connect(path)
@@ -15,7 +17,7 @@ def main(out_txt, out_json, dbs):
              "group by kernel_name, counter_name")
         for name, counter, n, val, dur in c.execute(q):
             rows.setdefault(name.split("(")[0], {})[counter] = (n, val, dur)
-    lines = ["# rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline (one pass per group)",
+    lines = [f"# rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --mode {mode} --steps 3 --warmup 1 (one pass per group)",
              "# per-dispatch averages; FETCH_SIZE/WRITE_SIZE in KiB as reported; duration in ns; SQ_* wave counters in quad-cycles",
              "# gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE under-reports wide coalesced reads by 2x -> doubled in the json"]
     for k, v in rows.items():
@@ -32,11 +34,21 @@ def main(out_txt, out_json, dbs):
             clk = act[1] / 8 / (act[2] * 1e-9) / 1e9
             mf = rg["SQ_VALU_MFMA_BUSY_CYCLES"][1] / 1024 / (act[1] / 8) if "SQ_VALU_MFMA_BUSY_CYCLES" in rg else None
             pairs = int(os.environ.get("P2P_PAIRS_PER_STEP", "16"))      # bench.py default: 16 pairs x 400 proposals
-            json.dump({"kernel": k.split("::")[-1], "proposals_per_launch": pairs * 400,
-                       "launch": f"{pairs * 400} proposals ({pairs} pairs x 400), 2 levels", "hbm_bytes_per_launch": fetch + write,
-                       "fetch_bytes_corrected_x2": fetch, "write_bytes": write, "effective_clock_ghz": clk,
-                       "mfma_busy_fraction": mf, "source": out_txt}, open(out_json, "w"), indent=1)
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            import bench
+            allrec = json.load(open(out_json)) if os.path.exists(out_json) else {}
+            if "kernel" in allrec:                                        # round-1 format (one un-keyed record)
+                allrec = {}
+            lds = None
+            if "SQ_LDS_BANK_CONFLICT" in rg and "SQ_LDS_IDX_ACTIVE" in rg and rg["SQ_LDS_IDX_ACTIVE"][1] > 0:
+                lds = rg["SQ_LDS_BANK_CONFLICT"][1] / rg["SQ_LDS_IDX_ACTIVE"][1]
+            allrec[mode] = {"kernel": k.split("::")[-1], "proposals_per_launch": pairs * 400, "config": "A",
+                            "launch": f"{pairs * 400} proposals ({pairs} pairs x 400), 2 levels",
+                            "hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected_x2": fetch, "write_bytes": write,
+                            "effective_clock_ghz": clk, "mfma_busy_fraction": mf, "lds_bank_conflict_fraction": lds,
+                            "source_hash": bench.source_hash(), "source": "profiles/" + os.path.basename(out_txt)}
+            json.dump(allrec, open(out_json, "w"), indent=1)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3:])
+    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4:])
