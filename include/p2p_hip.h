@@ -132,6 +132,16 @@ int p2p_coarse_matches_batch(const float *corr4d, const uint8_t *delta, int batc
                              int ksize, int upsample, int center, int64_t *matches_out, float *scores_out,
                              p2p_stream_t stream);
 
+/* filter_coarse -- reference networks/utils.py:38-72 without the `ptmax` sampling (which draws from the host's numpy
+ * RNG and therefore stays on the host): per batch item the lexicographically sorted distinct rows of matches [n,4]
+ * with the score of their first occurrence; `mutual` keeps rows that occur more than once; an empty selection leaves
+ * the list as it was; then rows with score > ncn_thres, again "or everything".
+ *   matches [B,n,4] int64, scores [B,n] fp32  ->  out_matches [B,n,4], out_scores [B,n] (first out_counts[b] rows
+ *   valid), out_counts [B] int32 on the device; out_counts[b] = -1 if a coordinate is negative or >= 2^15 (the caller
+ *   falls back to the host path).  n <= 8192 rows per item (P2P_EUNSUPPORTED beyond).                            */
+int p2p_filter_coarse_batch(const int64_t *matches, const float *scores, int batch, int n, float ncn_thres, int mutual,
+                            int64_t *out_matches, float *out_scores, int *out_counts, p2p_stream_t stream);
+
 /* ---- fine stage ------------------------------------------------------------------------------ */
 
 /* One image's feature pyramid levels feat_idx [0,1,2,3] (reference networks/resnet.py:138-157 with
@@ -168,6 +178,16 @@ int p2p_regress_batch(const p2p_regressor *reg1, const p2p_regressor *reg2, int 
                       const void *proposals, int is_float,
                       float *matches1, float *probs1, float *raw1,
                       float *matches2, float *probs2, float *raw2, p2p_stream_t stream);
+
+/* The same with the proposal counts in DEVICE memory (e.g. written by p2p_filter_coarse_batch): every item owns
+ * `stride` slots of the proposal and output arrays ([nitems*stride, ...]), of which the first dev_counts[i] are used;
+ * the other slots' outputs are left untouched.  Nothing has to come back to the host between the coarse and the fine
+ * stage.                                                                                                          */
+int p2p_regress_batch_dev(const p2p_regressor *reg1, const p2p_regressor *reg2, int nitems,
+                          const p2p_pyramid *im1, const p2p_pyramid *im2, const int *dev_counts, int stride,
+                          const void *proposals, int is_float,
+                          float *matches1, float *probs1, float *raw1,
+                          float *matches2, float *probs2, float *raw2, p2p_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -69,6 +69,9 @@ p2p_coarse_matches = _sig("p2p_coarse_matches", ctypes.c_int,
 p2p_coarse_matches_batch = _sig("p2p_coarse_matches_batch", ctypes.c_int,
                                 [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 8 +
                                 [ctypes.c_void_p, ctypes.c_void_p, c_stream])
+p2p_filter_coarse_batch = _sig("p2p_filter_coarse_batch", ctypes.c_int,
+                               [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int,
+                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_stream])
 p2p_regress = _sig("p2p_regress", ctypes.c_int,
                    [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Pyramid), ctypes.POINTER(Pyramid),
                     ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 6 + [c_stream])
@@ -77,13 +80,17 @@ p2p_regress_batch = _sig("p2p_regress_batch", ctypes.c_int,
                          [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(Pyramid), ctypes.POINTER(Pyramid),
                           ctypes.POINTER(ctypes.c_int), ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6 + [c_stream])
 
+p2p_regress_batch_dev = _sig("p2p_regress_batch_dev", ctypes.c_int,
+                             [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(Pyramid), ctypes.POINTER(Pyramid),
+                              ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6 + [c_stream])
+
 p2p_regressor_set_mode = _sig("p2p_regressor_set_mode", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int])
 p2p_regressor_get_mode = _sig("p2p_regressor_get_mode", ctypes.c_int, [ctypes.c_void_p])
 REGRESS_MODES = {"f32": 0, "bf16x2": 1, "bf16x3": 2}
 
 EXPORTS = ["p2p_version", "p2p_last_error", "p2p_ncn_create", "p2p_ncn_destroy", "p2p_regressor_create",
            "p2p_regressor_destroy", "p2p_coarse_workspace_bytes", "p2p_coarse_forward", "p2p_coarse_forward_batch",
-           "p2p_delta_unpack", "p2p_coarse_matches", "p2p_coarse_matches_batch", "p2p_regress", "p2p_regress_batch", "p2p_regressor_set_mode",
+           "p2p_delta_unpack", "p2p_coarse_matches", "p2p_coarse_matches_batch", "p2p_filter_coarse_batch", "p2p_regress", "p2p_regress_batch", "p2p_regress_batch_dev", "p2p_regressor_set_mode",
            "p2p_regressor_get_mode"]
 
 

@@ -1,0 +1,160 @@
+// filter_coarse on the device -- reference networks/utils.py:38-72 without the ptmax sampling (that one draws from
+// the host's numpy RNG and stays on the host): per batch item, the lexicographically sorted distinct rows of the
+// [n,4] int64 match list with the score of their first occurrence; `mutual` keeps rows that occur more than once;
+// if nothing is kept the list stays as it was; then rows with score > ncn_thres, again "or everything".
+// One work-group per item: packed 64-bit keys (4 x 16 bits, pixel coordinates are < 2^15) + original index in LDS,
+// bitonic sort, run detection, two order-preserving compactions.
+#include "p2p_common.h"
+
+namespace p2p {
+
+constexpr int FT = 1024;                      // threads per work-group
+constexpr int FILTER_MAX_ROWS = 8192;         // (8 + 4 + 4) bytes of LDS per padded row
+
+struct FilterArgs {
+    const long long *matches;                 // [B][n][4]
+    const float *scores;                      // [B][n]
+    int n, npad;                              // rows per item, next power of two
+    float thres;
+    int mutual;
+    long long *out_matches;                   // [B][n][4]
+    float *out_scores;                        // [B][n]
+    int *out_counts;                          // [B]; -1 = a coordinate did not fit the packed key (caller falls back)
+};
+
+// exclusive prefix sum of one int per thread over the work-group; returns the total through *total
+__device__ __forceinline__ int block_exclusive_scan(int v, int *wave_sums, int *total) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_sums[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        int s = (lane < FT / 64) ? wave_sums[lane] : 0;
+#pragma unroll
+        for (int d = 1; d < FT / 64; d <<= 1) {
+            const int o = __shfl_up(s, d);
+            if (lane >= d) s += o;
+        }
+        if (lane < FT / 64) wave_sums[lane] = s;      // inclusive over waves
+    }
+    __syncthreads();
+    const int base = wave ? wave_sums[wave - 1] : 0;
+    *total = wave_sums[FT / 64 - 1];
+    __syncthreads();                                  // wave_sums may be reused by the caller
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(FT) void filter_coarse_kernel(FilterArgs a) {
+    P2P_DYN_SHARED(unsigned char, fsm);
+    unsigned long long *key = (unsigned long long *)fsm;              // [npad]
+    int *idx = (int *)(fsm + (size_t)a.npad * 8);                      // [npad]  original row of a sorted position
+    int *pos = idx + a.npad;                                           // [npad]  scratch: list of kept source rows
+    __shared__ int wave_sums[FT / 64];
+    __shared__ int flag_bad;
+    const int tid = threadIdx.x, item = blockIdx.x;
+    const long long *rows = a.matches + (size_t)item * a.n * 4;
+    const float *sc = a.scores + (size_t)item * a.n;
+    long long *orow = a.out_matches + (size_t)item * a.n * 4;
+    float *osc = a.out_scores + (size_t)item * a.n;
+    if (tid == 0) flag_bad = 0;
+    __syncthreads();
+    for (int i = tid; i < a.npad; i += FT) {
+        unsigned long long k = ~0ull;
+        if (i < a.n) {
+            const long long x0 = rows[i * 4], x1 = rows[i * 4 + 1], x2 = rows[i * 4 + 2], x3 = rows[i * 4 + 3];
+            if ((unsigned long long)(x0 | x1 | x2 | x3) >= (1ull << 15)) flag_bad = 1;      // also catches negatives
+            k = ((unsigned long long)x0 << 48) | ((unsigned long long)x1 << 32) | ((unsigned long long)x2 << 16) |
+                (unsigned long long)x3;
+        }
+        key[i] = k;
+        idx[i] = i;
+    }
+    __syncthreads();
+    if (flag_bad) {
+        if (tid == 0) a.out_counts[item] = -1;
+        return;
+    }
+    // bitonic sort by (key, original index): equal rows stay in input order, so a run starts with its first occurrence
+    for (int size = 2; size <= a.npad; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < a.npad / 2; t += FT) {
+                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned long long kl = key[lo], kh = key[hi];
+                const int il = idx[lo], ih = idx[hi];
+                const bool greater = kl > kh || (kl == kh && il > ih);
+                if (greater == up) { key[lo] = kh; key[hi] = kl; idx[lo] = ih; idx[hi] = il; }
+            }
+            __syncthreads();
+        }
+    // stage 1: run starts (first occurrences in sorted order), with `mutual` only runs longer than one
+    const int per = (a.n + FT - 1) / FT, i0 = min(tid * per, a.n), i1 = min(i0 + per, a.n);
+    int mine = 0;
+    for (int i = i0; i < i1; ++i) {
+        const bool start = (i == 0) || key[i] != key[i - 1];
+        const bool more = (i + 1 < a.n) && key[i + 1] == key[i];
+        mine += start && (!a.mutual || more);
+    }
+    int nsel;
+    int at = block_exclusive_scan(mine, wave_sums, &nsel);
+    if (nsel > 0) {
+        for (int i = i0; i < i1; ++i) {
+            const bool start = (i == 0) || key[i] != key[i - 1];
+            const bool more = (i + 1 < a.n) && key[i + 1] == key[i];
+            if (start && (!a.mutual || more)) pos[at++] = idx[i];
+        }
+    } else {
+        nsel = a.n;                                  // nothing selected: the list stays as it was
+        for (int i = i0; i < i1; ++i) pos[i] = i;
+    }
+    __syncthreads();
+    // stage 2: score threshold on that list, "or everything"
+    const int per2 = (nsel + FT - 1) / FT, j0 = min(tid * per2, nsel), j1 = min(j0 + per2, nsel);
+    int pass = 0;
+    for (int j = j0; j < j1; ++j) pass += sc[pos[j]] > a.thres;
+    int npass;
+    int at2 = block_exclusive_scan(pass, wave_sums, &npass);
+    const bool all = (npass == 0);
+    if (all) at2 = j0;
+    for (int j = j0; j < j1; ++j) {
+        const int src = pos[j];
+        const float s = sc[src];
+        if (all || s > a.thres) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) orow[(size_t)at2 * 4 + q] = rows[(size_t)src * 4 + q];
+            osc[at2] = s;
+            ++at2;
+        }
+    }
+    if (tid == 0) a.out_counts[item] = all ? nsel : npass;
+}
+
+}  // namespace p2p
+
+using namespace p2p;
+
+extern "C" int p2p_filter_coarse_batch(const int64_t *matches, const float *scores, int batch, int n, float ncn_thres,
+                                       int mutual, int64_t *out_matches, float *out_scores, int *out_counts,
+                                       p2p_stream_t stream) {
+    P2P_REQUIRE(matches && scores && out_matches && out_scores && out_counts, P2P_EINVAL, "p2p_filter_coarse: null argument");
+    P2P_REQUIRE(batch >= 1 && batch <= 65535 && n >= 1, P2P_EINVAL, "p2p_filter_coarse: bad sizes");
+    P2P_REQUIRE(n <= FILTER_MAX_ROWS, P2P_EUNSUPPORTED, "p2p_filter_coarse: %d rows per item (device path holds %d)", n,
+                FILTER_MAX_ROWS);
+    int npad = 2;
+    while (npad < n) npad <<= 1;
+    const size_t lds = (size_t)npad * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        P2P_HIP_CHECK(hipFuncSetAttribute((const void *)filter_coarse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          FILTER_MAX_ROWS * 16));
+        attr_set = true;
+    }
+    FilterArgs a{(const long long *)matches, scores, n, npad, ncn_thres, mutual, (long long *)out_matches, out_scores, out_counts};
+    hipLaunchKernelGGL(filter_coarse_kernel, dim3(batch), dim3(FT), lds, (hipStream_t)stream, a);
+    return check_launch("filter_coarse_kernel");
+}

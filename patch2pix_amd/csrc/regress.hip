@@ -69,6 +69,7 @@ __global__ __launch_bounds__(NT, 2) void regress_kernel(RegressArgs args) {
     const int prop = blockIdx.x;
     int it = 0;
     while (it + 1 < args.nitems && prop >= args.start[it + 1]) ++it;
+    if (args.dev_counts && prop - args.start[it] >= args.dev_counts[it]) return;      // empty slot (whole work-group)
     const ItemDev &I = args.item[it];
 
     float *tiles = smem;
@@ -462,11 +463,13 @@ static RegDev to_dev(const p2p_regressor *r) {
     return d;
 }
 
-extern "C" int p2p_regress_batch(const p2p_regressor *reg1, const p2p_regressor *reg2, int nitems,
-                                 const p2p_pyramid *im1, const p2p_pyramid *im2, const int *counts,
-                                 const void *proposals, int is_float,
-                                 float *matches1, float *probs1, float *raw1,
-                                 float *matches2, float *probs2, float *raw2, p2p_stream_t stream) {
+// counts: per item, the number of slots in the concatenated arrays (host memory); dev_counts (optional, device
+// memory, indexed like counts): how many of those slots hold a proposal -- the remaining work-groups exit at once.
+static int regress_batch_impl(const p2p_regressor *reg1, const p2p_regressor *reg2, int nitems,
+                              const p2p_pyramid *im1, const p2p_pyramid *im2, const int *counts, const int *dev_counts,
+                              const void *proposals, int is_float,
+                              float *matches1, float *probs1, float *raw1,
+                              float *matches2, float *probs2, float *raw2, p2p_stream_t stream) {
     P2P_REQUIRE(reg1 && im1 && im2 && counts, P2P_EINVAL, "p2p_regress: null argument");
     P2P_REQUIRE(nitems >= 0, P2P_EINVAL, "p2p_regress: negative item count");
     long long total = 0;
@@ -515,6 +518,7 @@ extern "C" int p2p_regress_batch(const p2p_regressor *reg1, const p2p_regressor 
         for (int b = nb; b <= MAXB; ++b) a.start[b] = n;
         for (int b = nb; b < MAXB; ++b) a.item[b] = a.item[0];
         a.nitems = nb;
+        a.dev_counts = dev_counts ? dev_counts + i0 : nullptr;
         a.is_float = is_float; a.n = n; a.nlevels = reg2 ? 2 : 1;
         a.proposals = is_float ? (const void *)((const float *)proposals + (size_t)first_prop * 4)
                                : (const void *)((const long long *)proposals + (size_t)first_prop * 4);
@@ -538,6 +542,26 @@ extern "C" int p2p_regress_batch(const p2p_regressor *reg1, const p2p_regressor 
         first_prop += n;
     }
     return P2P_OK;
+}
+
+extern "C" int p2p_regress_batch(const p2p_regressor *reg1, const p2p_regressor *reg2, int nitems,
+                                 const p2p_pyramid *im1, const p2p_pyramid *im2, const int *counts,
+                                 const void *proposals, int is_float,
+                                 float *matches1, float *probs1, float *raw1,
+                                 float *matches2, float *probs2, float *raw2, p2p_stream_t stream) {
+    return regress_batch_impl(reg1, reg2, nitems, im1, im2, counts, nullptr, proposals, is_float, matches1, probs1, raw1,
+                              matches2, probs2, raw2, stream);
+}
+
+extern "C" int p2p_regress_batch_dev(const p2p_regressor *reg1, const p2p_regressor *reg2, int nitems,
+                                     const p2p_pyramid *im1, const p2p_pyramid *im2, const int *dev_counts, int stride,
+                                     const void *proposals, int is_float,
+                                     float *matches1, float *probs1, float *raw1,
+                                     float *matches2, float *probs2, float *raw2, p2p_stream_t stream) {
+    P2P_REQUIRE(dev_counts && stride >= 1 && nitems >= 0 && nitems <= 4096, P2P_EINVAL, "p2p_regress_batch_dev: bad argument");
+    std::vector<int> cap(nitems, stride);
+    return regress_batch_impl(reg1, reg2, nitems, im1, im2, cap.data(), dev_counts, proposals, is_float, matches1, probs1,
+                              raw1, matches2, probs2, raw2, stream);
 }
 
 extern "C" int p2p_regress(const p2p_regressor *reg1, const p2p_regressor *reg2,

@@ -24,6 +24,8 @@ struct ItemDev {
 struct RegressArgs {
     ItemDev item[MAXB];
     int start[MAXB + 1];          // proposal range of each item in the concatenated arrays
+    const int *dev_counts;        // optional: per item, how many of its slots hold a proposal (device memory; the
+                                  // host then only knows the capacity start[b+1] - start[b])
     int nitems;
     const void *proposals;
     int is_float, n, nlevels;

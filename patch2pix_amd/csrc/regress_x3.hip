@@ -122,6 +122,7 @@ __global__ __launch_bounds__(NT, 2) void regress_x3_kernel(RegressArgs args) {
     const int prop = blockIdx.x;
     int it = 0;
     while (it + 1 < args.nitems && prop >= args.start[it + 1]) ++it;
+    if (args.dev_counts && prop - args.start[it] >= args.dev_counts[it]) return;      // empty slot (whole work-group)
     const ItemDev &I = args.item[it];
 
     float *raw0 = (float *)(smb + XRAW0);

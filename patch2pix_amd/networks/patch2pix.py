@@ -292,6 +292,32 @@ class Patch2Pix(nn.Module):
             return fine, fine_scores, mid, mid_scores, coarse_matches
         return fine, fine_scores, coarse_matches
 
+    def predict_fine_device(self, feats1, feats2, ksize=2, ncn_thres=0.0, mutual=True):
+        """The whole path without a host round trip: coarse stage -> device-side filter_coarse -> both
+        regressors reading the proposal counts from device memory.  Returns padded device tensors
+        (fine [B,n,4], fine_scores [B,n], coarse [B,n,4] int64, counts int32 [B]); `unpad` turns them into the lists
+        predict_fine returns.  Not available for the training-time options (ptmax, panc > 1) and for images whose pixel
+        coordinates do not fit 15 bits -- use predict_fine_from_feats there."""
+        if self.panc != 1:
+            raise NotImplementedError("predict_fine_device: panc > 1 goes through predict_fine_from_feats")
+        if max(feats1[0].shape[-2:] + feats2[0].shape[-2:]) >= (1 << 15):
+            raise NotImplementedError("predict_fine_device: image sides must be below 32768 pixels")
+        _, mid_w, fine_w = self._weights()
+        corr4d, delta4d = self.forward_coarse_match(feats1[4], feats2[4], ksize=ksize)
+        matches_, score_ = self.cal_coarse_matches(corr4d, delta4d, ksize=ksize, upsample=self.upsample, center=True)
+        coarse, _, counts = ops.filter_coarse_batch(matches_, score_, ncn_thres, mutual)
+        nb = coarse.shape[0]
+        out = ops.regress_batch_dev(mid_w, fine_w, [[f[b] for f in feats1[:4]] for b in range(nb)],
+                                    [[f[b] for f in feats2[:4]] for b in range(nb)], coarse, counts)
+        return out["matches2"], out["probs2"], coarse, counts
+
+    @staticmethod
+    def unpad(fine, fine_scores, coarse, counts):
+        """One device-to-host copy of the counts, then per-item views: the (fine, scores, coarse) lists of predict_fine."""
+        n = counts.cpu().tolist()
+        return ([fine[b, :c] for b, c in enumerate(n)], [fine_scores[b, :c] for b, c in enumerate(n)],
+                [coarse[b, :c] for b, c in enumerate(n)])
+
     def predict_fine_from_feats(self, feats1, feats2, ksize=2, ncn_thres=0.0, mutual=True, return_all=False,
                                 ptmax=None):
         """predict_fine after the backbone: the part of the path that is HIP end to end.

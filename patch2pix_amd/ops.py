@@ -194,6 +194,63 @@ def coarse_matches(corr, delta, ksize, upsample, center=True, out_matches=None, 
     return m[0], sc[0]
 
 
+def filter_coarse_batch(matches, scores, ncn_thres=0.0, mutual=True):
+    """filter_coarse (networks/utils.py:38-72, no ptmax) on the device for a batch: matches [B,n,4] int64, scores [B,n]
+    fp32 -> (rows [B,n,4], scores [B,n], counts int32 [B]); the first counts[b] rows of item b are valid, in the
+    reference's order.  counts[b] == -1 asks for the host path (a coordinate outside [0, 2^15))."""
+    if matches.dtype != torch.int64 or matches.dim() != 3 or matches.shape[-1] != 4 or not matches.is_cuda:
+        raise TypeError("matches must be an int64 [B,n,4] tensor on the GPU")
+    scores = _f32c(scores, "scores")
+    matches = matches.contiguous()
+    nb, n, _ = matches.shape
+    dev = matches.device
+    out_m, out_s = torch.empty_like(matches), torch.empty_like(scores)
+    counts = torch.empty((nb,), dtype=torch.int32, device=dev)
+    if nb and n:
+        with torch.cuda.device(dev):
+            _lib.check(_lib.p2p_filter_coarse_batch(matches.data_ptr(), scores.data_ptr(), nb, n, float(ncn_thres),
+                                                    int(bool(mutual)), out_m.data_ptr(), out_s.data_ptr(),
+                                                    counts.data_ptr(), _stream()), "p2p_filter_coarse_batch")
+    else:
+        counts.zero_()
+    return out_m, out_s, counts
+
+
+def regress_batch_dev(reg1, reg2, pyrs1, pyrs2, proposals, counts, want_raw=False):
+    """regress_batch with the proposal counts in device memory: proposals [B,stride,4] (int64 or float32), counts int32
+    [B] on the GPU; every output is padded to [B,stride,...], rows beyond counts[b] are left uninitialised."""
+    nb, stride, _ = proposals.shape
+    dev = proposals.device
+    if proposals.dtype not in (torch.int64, torch.float32):
+        raise TypeError("proposals must be int64 or float32")
+    if counts.dtype != torch.int32 or counts.numel() != nb or not counts.is_cuda:
+        raise TypeError("counts must be an int32 [B] tensor on the GPU")
+    proposals = proposals.contiguous()
+    pyr_a, pyr_b, keep = (_lib.Pyramid * nb)(), (_lib.Pyramid * nb)(), []
+    for i in range(nb):
+        pa, ka = _pyramid(pyrs1[i])
+        pb, kb = _pyramid(pyrs2[i])
+        pyr_a[i], pyr_b[i] = pa, pb
+        keep.append((ka, kb))
+    two = reg2 is not None
+    out = {"matches1": torch.empty((nb, stride, 4), device=dev), "probs1": torch.empty((nb, stride), device=dev)}
+    if two:
+        out["matches2"], out["probs2"] = torch.empty((nb, stride, 4), device=dev), torch.empty((nb, stride), device=dev)
+    if want_raw:
+        out["raw1"] = torch.empty((nb, stride, 5), device=dev)
+        if two:
+            out["raw2"] = torch.empty((nb, stride, 5), device=dev)
+    g = lambda k: out[k].data_ptr() if k in out else None
+    if nb and stride:
+        with torch.cuda.device(dev):
+            _lib.check(_lib.p2p_regress_batch_dev(reg1.handle, reg2.handle if two else None, nb, pyr_a, pyr_b,
+                                                  counts.data_ptr(), stride, proposals.data_ptr(),
+                                                  int(proposals.is_floating_point()), g("matches1"), g("probs1"), g("raw1"),
+                                                  g("matches2"), g("probs2"), g("raw2"), _stream()), "p2p_regress_batch_dev")
+    del keep
+    return out
+
+
 def _pyramid(levels):
     if len(levels) != 4:
         raise ValueError("a pyramid is the 4 maps of feat_idx [0,1,2,3]")

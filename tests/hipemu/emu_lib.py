@@ -113,3 +113,19 @@ def regress(emu, reg1, reg2, pyr1, pyr2, proposals):
                                      out["raw2"].data_ptr() if two else None, None), "p2p_regress_batch")
     del ka, kb
     return out
+
+
+def filter_coarse_batch(emu, matches, scores, thres, mutual):
+    """matches [B,n,4] int64, scores [B,n] fp32 (CPU) -> list of (rows, scores) per item, or None where the kernel
+    asked for the host fallback."""
+    matches, scores = matches.contiguous(), scores.contiguous()
+    nb, n, _ = matches.shape
+    om, osc = torch.empty_like(matches), torch.empty_like(scores)
+    cnt = torch.empty(nb, dtype=torch.int32)
+    check(emu, emu.p2p_filter_coarse_batch(ptr(matches), ptr(scores), nb, n, float(thres), int(mutual), ptr(om), ptr(osc),
+                                           ptr(cnt), None), "p2p_filter_coarse_batch")
+    out = []
+    for b in range(nb):
+        c = int(cnt[b])
+        out.append(None if c < 0 else (om[b, :c].clone(), osc[b, :c].clone()))
+    return out

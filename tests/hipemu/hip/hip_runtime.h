@@ -104,6 +104,14 @@ template <class T> static inline T __shfl_xor(T v, int mask) {
     return out;
 }
 
+template <class T> static inline T __shfl_up(T v, int delta) {
+    const unsigned char *all = hipemu::wave_gather(&v, sizeof(T));
+    const int lane = hipemu::ctx().thread.x & 63;
+    T out = v;
+    if (lane >= delta) memcpy(&out, all + (lane - delta) * sizeof(T), sizeof(T));
+    return out;
+}
+
 // v_mfma_f32_32x32x2_f32: D = A(32x2) B(2x32) + C.  Lane l holds A[l&31][l>>5], B[l>>5][l&31]; register r of
 // C/D is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
 typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));

@@ -789,3 +789,19 @@ print('ROUTE_OK', m.shape, m.dtype, s.dtype, c.shape)
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
     assert res.returncode == 0 and "ROUTE_OK" in res.stdout, res.stderr[-2000:]
     assert "float64 float32" in res.stdout
+
+
+def test_device_side_filter_path_equals_host_path(dev):
+    """predict_fine_device (filter_coarse on the device, regressors reading the counts from device memory, no host round
+    trip) returns exactly what predict_fine_from_feats returns through the host-side filter."""
+    from patch2pix_amd.utils.eval import model_helper
+    net = model_helper.load_model(synthetic.make_checkpoint(0), lprint=lambda *a: None)
+    pairs = [synthetic.make_correlated_pyramids(900 + i, 128, 160) for i in range(3)]
+    f1 = [torch.stack([p[0][j] for p in pairs]).to(dev) for j in range(5)]
+    f2 = [torch.stack([p[1][j] for p in pairs]).to(dev) for j in range(5)]
+    for mutual, thres in ((True, 0.0), (False, 0.0), (True, 0.9)):
+        fine, scores, coarse = net.predict_fine_from_feats(f1, f2, ksize=2, ncn_thres=thres, mutual=mutual)
+        dfine, dscores, dcoarse = net.unpad(*net.predict_fine_device(f1, f2, ksize=2, ncn_thres=thres, mutual=mutual))
+        for b in range(3):
+            assert torch.equal(dcoarse[b], coarse[b]), (mutual, thres, b)
+            assert torch.equal(dfine[b], fine[b]) and torch.equal(dscores[b], scores[b]), (mutual, thres, b)

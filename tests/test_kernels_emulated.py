@@ -237,3 +237,62 @@ def test_regressor_on_image_sizes_that_are_not_multiples_of_8(mode, emu, sd):
     assert (out["raw1"] - ref_raw).abs().max() < 5e-5
     assert (out["matches1"] - ref_mid).abs().max() <= COORD_TOL
     assert (out["probs1"] - ref_p).abs().max() <= SCORE_TOL
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_device_filter_coarse_against_oracle(seed, emu):
+    """p2p_filter_coarse_batch (sort-unique, mutual, threshold, both keep-all fallbacks) == networks/utils.py:38-72."""
+    g = torch.Generator().manual_seed(seed)
+    n = int(torch.randint(1, 600, (1,), generator=g))
+    distinct = int(torch.randint(1, max(2, n), (1,), generator=g))
+    span, B = [8, 200, 32767][seed % 3], 1 + seed % 3
+    pool = torch.randint(0, span + 1, (B, distinct, 4), generator=g)
+    rows = torch.gather(pool, 1, torch.randint(0, distinct, (B, n), generator=g)[:, :, None].expand(-1, -1, 4))
+    scores = torch.rand(B, n, generator=g)
+    for mutual in (True, False):
+        for thres in (0.0, 0.5, 2.0):
+            got = emu_lib.filter_coarse_batch(emu, rows, scores, thres, mutual)
+            for b in range(B):
+                r, rs = orc.filter_coarse(rows[b], scores[b], thres, mutual)
+                assert got[b] is not None and torch.equal(got[b][0], r) and torch.equal(got[b][1], rs)
+    for bad in ([70000, 1, 2, 3], [-1, 1, 2, 3]):          # outside the packed key: the kernel asks for the host path
+        assert emu_lib.filter_coarse_batch(emu, torch.tensor([[bad, [1, 2, 3, 4]]]), torch.rand(1, 2), 0.0, True) == [None]
+
+
+def test_regress_with_device_counts(emu, sd):
+    """p2p_regress_batch_dev: every item owns `stride` slots, the first counts[i] hold proposals; used slots equal the
+    per-item call bit for bit, the others are not touched."""
+    import ctypes
+    from patch2pix_amd import _lib as real
+    sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+    mid = emu_lib.regressor_create(emu, sub("regress_mid."), "bf16x2")
+    fine = emu_lib.regressor_create(emu, sub("regress_fine."), "bf16x2")
+    sizes, counts, stride = [(16, 24), (24, 16), (8, 8)], [2, 0, 1], 3
+    g = torch.Generator().manual_seed(4)
+    pyr1 = [synthetic.make_pyramid(200 + i, h, w)[:4] for i, (h, w) in enumerate(sizes)]
+    pyr2 = [synthetic.make_pyramid(300 + i, h, w)[:4] for i, (h, w) in enumerate(sizes)]
+    props = torch.zeros(len(sizes), stride, 4, dtype=torch.int64)
+    for i, ((h, w), c) in enumerate(zip(sizes, counts)):
+        props[i, :c] = torch.stack([torch.randint(0, w + 1, (c,), generator=g), torch.randint(0, h + 1, (c,), generator=g),
+                                    torch.randint(0, w + 1, (c,), generator=g), torch.randint(0, h + 1, (c,), generator=g)], 1)
+    arr_a, arr_b, keep = (real.Pyramid * len(sizes))(), (real.Pyramid * len(sizes))(), []
+    for i in range(len(sizes)):
+        for arr, pyr in ((arr_a, pyr1[i]), (arr_b, pyr2[i])):
+            lv = [t.contiguous() for t in pyr]
+            keep.append(lv)
+            for j in range(4):
+                arr[i].level[j] = lv[j].data_ptr()
+            arr[i].height, arr[i].width = lv[0].shape[-2:]
+    n, mark = len(sizes) * stride, -777.0
+    m1, p1, m2, p2 = torch.full((n, 4), mark), torch.full((n,), mark), torch.full((n, 4), mark), torch.full((n,), mark)
+    cnt = torch.tensor(counts, dtype=torch.int32)
+    emu_lib.check(emu, emu.p2p_regress_batch_dev(mid, fine, len(sizes), arr_a, arr_b, cnt.data_ptr(), stride,
+                                                 props.data_ptr(), 0, m1.data_ptr(), p1.data_ptr(), None, m2.data_ptr(),
+                                                 p2.data_ptr(), None, None), "p2p_regress_batch_dev")
+    for i, c in enumerate(counts):
+        used, rest = slice(i * stride, i * stride + c), slice(i * stride + c, (i + 1) * stride)
+        if c:
+            single = emu_lib.regress(emu, mid, fine, pyr1[i], pyr2[i], props[i, :c].contiguous())
+            assert torch.equal(m1[used], single["matches1"]) and torch.equal(m2[used], single["matches2"])
+            assert torch.equal(p1[used], single["probs1"]) and torch.equal(p2[used], single["probs2"])
+        assert bool((m1[rest] == mark).all() and (m2[rest] == mark).all() and (p2[rest] == mark).all())
