@@ -63,6 +63,9 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
 
 // 8 consecutive K values of one row (two 16-byte LDS reads), scaled by s, as three bf16x8 planes
 __device__ __forceinline__ void split3(const f32x4 &xa, const f32x4 &xb, float s, f32x4 &p0, f32x4 &p1, f32x4 &p2) {
+#ifdef XP_NOSPLIT                       // timing experiment (wrong results): how much of the split is hidden
+    p0 = xa; p1 = xb; p2 = xa; return;
+#endif
     const float x[8] = {xa[0] * s, xa[1] * s, xa[2] * s, xa[3] * s, xb[0] * s, xb[1] * s, xb[2] * s, xb[3] * s};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -80,37 +83,50 @@ __device__ __forceinline__ void split3(const f32x4 &xa, const f32x4 &xb, float s
 
 #define XMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
-// raw fp32 A fragments of one slab: P0/P1 = this lane's byte address for m-tile 0/1
-#define XLOADA(R, P0, P1)                                                                \
-    R[0] = *(const f32x4 *)(P0); R[1] = *(const f32x4 *)((P0) + 16);                     \
-    R[2] = *(const f32x4 *)(P1); R[3] = *(const f32x4 *)((P1) + 16);
-// S[0..2] planes of m-tile 0, S[3..5] of m-tile 1
-#define XSPLIT(S, R, SC0, SC1)                                                           \
-    split3(R[0], R[1], (SC0), S[0], S[1], S[2]); split3(R[2], R[3], (SC1), S[3], S[4], S[5]);
+// raw fp32 A fragment (8 K values of this lane's row) of one m-tile: two 16-byte LDS reads
+#define XLOADR(R, P) R[0] = *(const f32x4 *)(P); R[1] = *(const f32x4 *)((P) + 16);
 // weights of the unit `AHEAD` units after the current stream position: 3 planes
 #define XLOADB(BUF, AHEAD)                                                               \
     _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) BUF[q_] = bp[(AHEAD) * 192 + q_ * 64];
-// one unit: 6 products x 2 m-tiles, smallest terms first
-#define XUNIT(C0, C1, S, BQ)                                                             \
-    C0 = XMFMA(S[2], BQ[0], C0); C1 = XMFMA(S[5], BQ[0], C1);                            \
-    C0 = XMFMA(S[1], BQ[1], C0); C1 = XMFMA(S[4], BQ[1], C1);                            \
-    C0 = XMFMA(S[0], BQ[2], C0); C1 = XMFMA(S[3], BQ[2], C1);                            \
-    C0 = XMFMA(S[1], BQ[0], C0); C1 = XMFMA(S[4], BQ[0], C1);                            \
-    C0 = XMFMA(S[0], BQ[1], C0); C1 = XMFMA(S[3], BQ[1], C1);                            \
-    C0 = XMFMA(S[0], BQ[0], C0); C1 = XMFMA(S[3], BQ[0], C1);
-// Two consecutive slabs = four units.  On entry R holds the raw A of the first slab and B0/B1 the weights of
-// its two units; loads run two units ahead into the buffer consumed two units ago (never the one the matrix
-// pipe has just read).  (N0,N1) = A addresses of the second slab, (M0,M1) = of the slab after that.
+// 12 MFMAs of one m-tile (planes SP) against the weights of both n-tiles: 6 products each, smallest terms first;
+// the two accumulators alternate
+#define XHALF(CU0, CU1, SP, BU0, BU1)                                                    \
+    CU0 = XMFMA(SP[2], BU0[0], CU0); CU1 = XMFMA(SP[2], BU1[0], CU1);                    \
+    CU0 = XMFMA(SP[1], BU0[1], CU0); CU1 = XMFMA(SP[1], BU1[1], CU1);                    \
+    CU0 = XMFMA(SP[0], BU0[2], CU0); CU1 = XMFMA(SP[0], BU1[2], CU1);                    \
+    CU0 = XMFMA(SP[1], BU0[0], CU0); CU1 = XMFMA(SP[1], BU1[0], CU1);                    \
+    CU0 = XMFMA(SP[0], BU0[1], CU0); CU1 = XMFMA(SP[0], BU1[1], CU1);                    \
+    CU0 = XMFMA(SP[0], BU0[0], CU0); CU1 = XMFMA(SP[0], BU1[0], CU1);
+// Software pipeline inside a wave.  The matrix pipe takes 32 cycles per MFMA and a wave issues in order, so a wave
+// that first splits a whole slab (88 VALU operations) and then issues its 24 MFMAs leaves the pipe idle while it --
+// and the other wave of the SIMD, which runs the same code in step -- does VALU work (first version: pipe 55 % busy).
+// Here every group of 12 MFMAs (one m-tile) carries the split of the OTHER m-tile's next fragment in its shadow:
+//   phase A:  MFMAs of m-tile 0 (planes S0) || LDS read of the next slab's m-tile-0 fragment, split of R1 -> S1,
+//             weight loads of the next slab's first unit
+//   phase B:  MFMAs of m-tile 1 (planes S1) || LDS read of the next slab's m-tile-1 fragment, split of R0 -> S0,
+//             weight loads of the next slab's second unit
+// sched_group_barrier pins the interleave (1 MFMA, then up to 4 VALU; the loads at the head of the phase).
+// Weights: (BC0, BC1) = this slab's two units, (BN0, BN1) = the next slab's, loaded one slab ahead (>= 768 matrix-pipe
+// cycles) into the buffers the previous slab used.
+#ifndef XP_VALU
+#define XP_VALU 4                       // VALU operations placed behind each MFMA (tools/ab_variants.sh)
+#endif
+#define XPIPE()                                                                          \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);             \
+    _Pragma("unroll") for (int g_ = 0; g_ < 12; ++g_) {                                                              \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, XP_VALU, 0); }
+#define XSLAB(N0, N1, SC0, SC1, BC0, BC1, BN0, BN1, AH)                                   \
+    { XLOADR(R0, N0) XLOADB(BN0, AH) split3(R1[0], R1[1], (SC1), S1[0], S1[1], S1[2]);                               \
+      XHALF(acc00, acc01, S0, BC0, BC1) XPIPE() __builtin_amdgcn_sched_barrier(0);                                    \
+      XLOADR(R1, N1) XLOADB(BN1, AH + 1) split3(R0[0], R0[1], (SC0), S0[0], S0[1], S0[2]);                            \
+      XHALF(acc10, acc11, S1, BC0, BC1) XPIPE() __builtin_amdgcn_sched_barrier(0); }
+// Two consecutive slabs = four units.  On entry S0 holds the planes of the first slab's m-tile 0, R1 the raw
+// fragment of its m-tile 1 (XPRO), and B0/B1 the weights of its two units.  (N0,N1) = A addresses of the second
+// slab, (M0,M1) = of the slab after that.
 #define XSLAB2(N0, N1, M0, M1, SC0, SC1)                                                  \
-    { XSPLIT(S, R, SC0, SC1) XLOADA(R, N0, N1) XLOADB(B2, 2) __builtin_amdgcn_sched_barrier(0);      \
-      XUNIT(acc00, acc10, S, B0) __builtin_amdgcn_sched_barrier(0);                                   \
-      XLOADB(B3, 3) __builtin_amdgcn_sched_barrier(0);                                                \
-      XUNIT(acc01, acc11, S, B1) __builtin_amdgcn_sched_barrier(0);                                   \
-      XSPLIT(S, R, SC0, SC1) XLOADA(R, M0, M1) XLOADB(B0, 4) __builtin_amdgcn_sched_barrier(0);      \
-      XUNIT(acc00, acc10, S, B2) __builtin_amdgcn_sched_barrier(0);                                   \
-      XLOADB(B1, 5) __builtin_amdgcn_sched_barrier(0);                                                \
-      XUNIT(acc01, acc11, S, B3) __builtin_amdgcn_sched_barrier(0);                                   \
-      bp += 4 * 192; }
+    { XSLAB(N0, N1, SC0, SC1, B0, B1, B2, B3, 2) XSLAB(M0, M1, SC0, SC1, B2, B3, B0, B1, 4) bp += 4 * 192; }
+// start of a run of slabs: fragments of its first slab
+#define XPRO(P0, P1, SC0) { XLOADR(R0, P0) XLOADR(R1, P1) split3(R0[0], R0[1], (SC0), S0[0], S0[1], S0[2]); }
 
 __global__ __launch_bounds__(NT, 2) void regress_x3_kernel(RegressArgs args) {
     P2P_DYN_SHARED(unsigned char, smb);
@@ -264,14 +280,14 @@ __global__ __launch_bounds__(NT, 2) void regress_x3_kernel(RegressArgs args) {
 
         // ------------------------------------------------------------ conv1: 3x3, stride 2, pad 1
         f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-        f32x4 B0[3], B1[3], B2[3], B3[3], R[4], S[6];
+        f32x4 B0[3], B1[3], B2[3], B3[3], R0[2], R1[2], S0[3], S1[3];
         {
             const f32x4 *bp = (const f32x4 *)R_.wx1 + (size_t)wave * (S1_UNITS + XPF) * 192 + lane;
             XLOADB(B0, 0) XLOADB(B1, 1)
             {   // level 0 of both images: 4 slabs of the pre-scaled block
                 const unsigned char *p0 = smb + XA0 + l31 * XA0ST + half * 32;
                 const unsigned char *p1 = p0 + 32 * XA0ST;
-                XLOADA(R, p0, p1)
+                XPRO(p0, p1, 1.0f)
                 XSLAB2(p0 + 64, p1 + 64, p0 + 128, p1 + 128, 1.0f, 1.0f)
                 XSLAB2(p0 + 192, p1 + 192, p0, p1, 1.0f, 1.0f)
             }
@@ -309,7 +325,7 @@ __global__ __launch_bounds__(NT, 2) void regress_x3_kernel(RegressArgs args) {
                     const unsigned char *a0 = smb + ab[0][0], *a1 = smb + ab[1][0];
                     const unsigned char *b0 = smb + ab[0][1], *b1 = smb + ab[1][1];
                     const unsigned char *c0 = smb + ab[0][2], *c1 = smb + ab[1][2];
-                    XLOADA(R, a0, a1)
+                    XPRO(a0, a1, sc[0])
                     // level 1 (64 ch), level 2 (64 ch), level 3 (128 ch): slabs of 16 channels = 64 bytes
                     XSLAB2(a0 + 64, a1 + 64, a0 + 128, a1 + 128, sc[0], sc[1])
                     XSLAB2(a0 + 192, a1 + 192, b0, b1, sc[0], sc[1])
@@ -359,7 +375,7 @@ __global__ __launch_bounds__(NT, 2) void regress_x3_kernel(RegressArgs args) {
                 const bool ok1 = okx && (oy + 4 < 8);
                 const unsigned char *p0 = smb + (ok0 ? oy * 8 + ox : 64) * XHPIX + half * 32;
                 const unsigned char *p1 = smb + (ok1 ? (oy + 4) * 8 + ox : 64) * XHPIX + half * 32;
-                XLOADA(R, p0, p1)
+                XPRO(p0, p1, 1.0f)
 #pragma unroll 1
                 for (int g = 0; g < 16; ++g) {       // 32 slabs of 16 channels = 64 bytes
                     const int gn = (g < 15) ? g + 1 : 15;

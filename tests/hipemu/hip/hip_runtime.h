@@ -95,6 +95,7 @@ static inline float unsafeAtomicAdd(float *p, float v) {
 }
 #define __builtin_amdgcn_readfirstlane(x) (x)      /* only applied to wave-uniform values in these kernels */
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(mask, n, id) ((void)0)
 #define __builtin_amdgcn_s_memtime() (0ull)
 
 template <class T> static inline T __shfl_xor(T v, int mask) {

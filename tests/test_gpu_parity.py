@@ -223,8 +223,13 @@ def _model(dev):
 
 
 def _near_integer_rows(mid, eps=2e-4):
+    """Rows with a coordinate within eps of an integer without being one: trunc() (networks/utils.py:19) of a value
+    that differs in the last bits may land on the other side.  EXACT integers are stable and not counted: they are the
+    clamp bounds 0 / W / H, or base - 8 where relu() zeroed the raw output (patch2pix.py:141-145: the coordinate is
+    base - 8 + 16 tanh(relu(o)) >= base - 8, so a differing last bit of o can only move it upwards, never across)."""
     frac = mid - mid.floor()
-    return ((frac < eps) | (frac > 1 - eps)).any(dim=1)
+    near = ((frac > 0) & (frac < eps)) | (frac > 1 - eps)
+    return near.any(dim=1)
 
 
 @pytest.mark.parametrize("name", gu.PAIR_CASES)
@@ -387,21 +392,36 @@ def test_benched_batch_path_vs_oracle(mode, dev):
         ticket = net.coarse_async(f1, f2, ksize=2)
         fine, fine_s, mid, mid_s, coarse = net.fine_from_ticket(ticket, 0.0, True, return_all=True, ptmax=ptmax)
     torch.cuda.synchronize()
+    from adjudicate import differing_rows_are_near_ties
     rng = np.random.RandomState(99)                     # the product draws from the global numpy RNG, pair after pair
     worst = dict(mid=0.0, fine=0.0, score=0.0)
+    near_ties = 0
+    n64 = None
     with torch.no_grad():
         for b in range(B if mode == MODES[0] else 3):   # all 16 pairs in the default mode, 3 in the others (CPU time)
             rc, rd = orc.coarse_forward(pairs[b][0][4], pairs[b][1][4], 2, o_ncn)
             rm, rs = orc.cal_coarse_matches(rc, rd, 2, 8)
-            assert torch.equal(ticket["matches"][b].cpu(), rm), f"pair {b}: coarse rows differ"
-            cm, _ = orc.filter_coarse(rm, rs, 0.0, True, ptmax=ptmax, rng=rng)
-            assert torch.equal(coarse[b].cpu(), cm), f"pair {b}: sampled proposals differ"
+            got_rows = ticket["matches"][b].cpu()
+            cm, _ = orc.filter_coarse(rm, rs, 0.0, True, ptmax=ptmax, rng=rng)       # keeps the RNG streams in step
+            if torch.equal(got_rows, rm):
+                assert torch.equal(coarse[b].cpu(), cm), f"pair {b}: sampled proposals differ"
+            else:
+                # a differing row must be a near-tie in an fp64 evaluation (tests/adjudicate.py); the proposals then
+                # differ legitimately and the fine stage is compared on the kernel's own proposals
+                if n64 is None:
+                    n64, _, _ = orc.split_params(ckpt_sd, torch.float64)
+                c64, _ = orc.coarse_forward(pairs[b][0][4].double(), pairs[b][1][4].double(), 2, n64)
+                nd, gap = differing_rows_are_near_ties(got_rows, rm, c64, feats=(pairs[b][0][4], pairs[b][1][4]))
+                print(f"\npair {b}: {nd} of {rm.shape[0]} coarse rows differ from the fp32 oracle, near-ties in fp64 (gap {gap:.1e})")
+                near_ties += nd
+                cm = coarse[b].cpu()
             ref_mid, ref_mp, _ = orc.fine_level(pairs[b][0][:4], pairs[b][1][:4], cm, mid_p)
             ref_fine, ref_fp, _ = orc.fine_level(pairs[b][0][:4], pairs[b][1][:4], mid[b].cpu(), fine_p)
             worst["mid"] = max(worst["mid"], (mid[b].cpu() - ref_mid).abs().max().item())
             worst["fine"] = max(worst["fine"], (fine[b].cpu() - ref_fine).abs().max().item())
             worst["score"] = max(worst["score"], (mid_s[b].cpu() - ref_mp).abs().max().item(),
                                  (fine_s[b].cpu() - ref_fp).abs().max().item())
+    assert near_ties <= 4, f"{near_ties} near-tie rows in {B} pairs"
     print(f"\n{mode}: max |d mid| {worst['mid']:.2e} px, |d fine| {worst['fine']:.2e} px, |d score| {worst['score']:.2e}")
     assert worst["mid"] <= COORD_TOL and worst["fine"] <= COORD_TOL and worst["score"] <= SCORE_TOL
 
