@@ -719,7 +719,7 @@ def test_real_image_pairs(name, imsize, dev, capsys):
         c64, _ = orc.coarse_forward(pyr1[4].double(), pyr2[4].double(), 2, n64)
     # with the random-init checkpoint the consensus volume of a real pair is nearly flat: a differing row must be a
     # near-tie in the fp64 volume (tests/adjudicate.py); everything else must be equal
-    nflip, worst = differing_rows_are_near_ties(ticket["matches"][0].cpu(), rm, c64)
+    nflip, worst = differing_rows_are_near_ties(ticket["matches"][0].cpu(), rm, c64, feats=(pyr1[4], pyr2[4]))
     # fine stage on the kernel's own proposals against the oracle (identical pyramids, identical proposals)
     with torch.no_grad():
         ref_mid, ref_mp, _ = orc.fine_level(pyr1[:4], pyr2[:4], coarse[0].cpu(), mid_p)
