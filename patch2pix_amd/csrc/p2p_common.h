@@ -37,8 +37,23 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 #ifndef P2P_OPAQUE                 // make a VGPR value opaque to the optimiser (stops hoisting of lane-only index math)
 #define P2P_OPAQUE(v) asm volatile("" : "+v"(v))
 #endif
+#ifndef P2P_OPAQUE_S               // the same for a wave-uniform value in SGPRs (keeps an address computation on the scalar unit)
+#define P2P_OPAQUE_S(v) asm volatile("" : "+s"(v))
+#endif
+#ifndef P2P_LANE_ID                // lane index inside the wave, recomputed from the hardware (v_mbcnt) instead of kept in a register
+#define P2P_LANE_ID() ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
+#endif
 #ifndef P2P_DYN_SHARED             // the dynamic LDS allocation of a kernel, 16-byte aligned
 #define P2P_DYN_SHARED(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
+#endif
+
+#ifndef P2P_WAVE_SYNC              // hand-over of LDS data between the lanes of ONE wave (LDS operations of a wave execute in order)
+#define P2P_WAVE_SYNC()                                        \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
 #endif
 
 // Check the launch that was just issued (asynchronous errors surface at the next sync).

@@ -143,7 +143,7 @@ int launch_regress_split(const RegressArgs &a, int n, hipStream_t stream);
 void split_conv1_index(int slab, int half, int j, int &ch, int &tap);   // K layout of conv1 shared by the bf16 kernels
 
 // regress_x3.hip: unit = (slab of 16 K, n-tile), three bf16 planes = 3 KiB per (wave, unit); stream order [slab][n-tile]
-constexpr int XPF = 4;                   // units the weight prefetch may run past the end of a stream
+constexpr int XPF = 8;                   // units the weight prefetch may run past the end of a stream
 constexpr size_t WX1_FLOATS = (size_t)8 * (S1_UNITS + XPF) * 768;
 constexpr size_t WX2_FLOATS = (size_t)8 * (S2_UNITS + XPF) * 768;
 void pack_x3_weights(const float *conv1_w, const float *conv2_w, float *wx1, float *wx2);      // host

@@ -38,7 +38,9 @@ def differing_rows_are_near_ties(rows_got, rows_ref, corr64, ksize=2, tol=3e-5, 
             vg = float((na[:, pg[1], pg[0]] * nb_[:, pg[3], pg[2]]).sum())
             vr = float((na[:, pr[1], pr[0]] * nb_[:, pr[3], pr[2]]).sum())
             worst_reloc = max(worst_reloc, abs(vg - vr))
-        assert worst_reloc < 5e-7, f"relocalisation differs and the two positions are {worst_reloc:.2e} apart in fp64"
+        # two correct fp32 evaluations of a 256-term dot product of unit vectors differ by ~sqrt(256) * 2^-24 = 1e-6
+        # (any summation order; bound 256 * 2^-24 = 1.5e-5): a gap below 2e-6 in fp64 cannot be decided in fp32
+        assert worst_reloc < 2e-6, f"relocalisation differs and the two positions are {worst_reloc:.2e} apart in fp64"
         keep = ~same_cell
         bad, ag, bg, cg, dg, ar, br, cr, dr = bad[keep], ag[keep], bg[keep], cg[keep], dg[keep], ar[keep], br[keep], cr[keep], dr[keep]
         if bad.numel() == 0:

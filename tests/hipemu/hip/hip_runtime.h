@@ -25,7 +25,10 @@
 
 // ---- overrides of the two indirections in csrc/p2p_common.h
 #define P2P_OPAQUE(v) asm volatile("" : "+r"(v))
+#define P2P_OPAQUE_S(v) asm volatile("" : "+r"(v))
+#define P2P_LANE_ID() ((int)(hipemu::ctx().thread.x & 63))
 #define P2P_DYN_SHARED(T, name) T *name = (T *)hipemu::dynamic_shared()
+#define P2P_WAVE_SYNC() do { char z_ = 0; (void)hipemu::wave_gather(&z_, 1); } while (0)   /* the lanes are fibers: rendezvous */
 
 struct dim3 {
     unsigned x, y, z;
@@ -97,6 +100,8 @@ static inline float unsafeAtomicAdd(float *p, float v) {
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(mask, n, id) ((void)0)
 #define __builtin_amdgcn_s_memtime() (0ull)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_barrier() hipemu::sync_block()
 
 template <class T> static inline T __shfl_xor(T v, int mask) {
     const unsigned char *all = hipemu::wave_gather(&v, sizeof(T));

@@ -5,6 +5,9 @@ from patch2pix_amd import ops
 from patch2pix_amd.utils import synthetic
 dev = torch.device("cuda:0")
 sd = synthetic.make_state_dict(0, backbone=False)
+if os.environ.get("ZERO_W"):      # power experiment: all-zero convolution weights (same instruction stream, no operand toggling)
+    for k in list(sd):
+        if ".conv.0." in k or ".conv.2." in k: sd[k] = sd[k] * 0
 sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
 mid = ops.RegressorWeights(sub("regress_mid."), dev); fine = ops.RegressorWeights(sub("regress_fine."), dev)
 H, W, n = 480, 640, int(os.environ.get("NPROP", "2000"))
@@ -18,8 +21,8 @@ for mode in sys.argv[1:]:
     for _ in range(2): ops.regress(mid, fine, g1, g2, props)
     torch.cuda.synchronize()
     ts = []
-    for _ in range(5):
+    for _ in range(int(os.environ.get('NITER', '5'))):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); ops.regress(mid, fine, g1, g2, props); b.record(); torch.cuda.synchronize()
         ts.append(a.elapsed_time(b))
-    print(f"{mode} rot={os.environ.get('P2P_SPLIT_ROT','1')} n={n}: median {sorted(ts)[2]:.3f} ms  min {min(ts):.3f}", flush=True)
+    print(f"{mode} rot={os.environ.get('P2P_SPLIT_ROT','1')} n={n}: median {sorted(ts)[len(ts)//2]:.3f} ms  min {min(ts):.3f}", flush=True)
