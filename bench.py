@@ -180,7 +180,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from patch2pix_amd import ops
-    from patch2pix_amd.gather import gather_matches
+    from patch2pix_amd.gather import gather_matches, pack_results
     from patch2pix_amd.utils import synthetic
     from patch2pix_amd.utils.eval import model_helper
 
@@ -234,12 +234,7 @@ def main():
         nrows = None
         if with_gather:
             # final gather of the match arrays (the only inter-GPU exchange of the path)
-            rows, ids = [], []
-            for i, (fine, score, coarse) in enumerate(results):
-                for b in range(B):
-                    rows.append(torch.cat([fine[b], score[b][:, None], coarse[b].float()], dim=1))
-                    ids.append(torch.full((fine[b].shape[0],), (i * world + rank) * B + b, dtype=torch.int64, device=dev))
-            all_rows, all_ids = gather_matches(torch.cat(rows), torch.cat(ids))
+            all_rows, all_ids = gather_matches(*pack_results(results, rank, world, B))
             nrows = all_rows.shape[0]
             assert all_ids.dtype == torch.int64 and all_ids.shape[0] == nrows
         barrier()

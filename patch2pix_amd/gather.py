@@ -11,6 +11,22 @@ def shard_pairs(num_pairs, rank, world):
     return list(range(rank, num_pairs, world))
 
 
+def pack_results(results, rank, world, pairs_per_step):
+    """What a rank contributes to the final gather: `results` = its steps, each a (fine, score, coarse) triple of
+    per-pair lists ([n,4] fp32, [n] fp32, [n,4] int64).  Returns (rows [M,9] fp32 = fine, score, coarse; ids [M] int64);
+    the global id of pair b of step i of rank r is (i * world + r) * pairs_per_step + b, i.e. steps are dealt
+    round-robin over the ranks like `shard_pairs` deals pairs."""
+    rows, ids = [], []
+    for i, (fine, score, coarse) in enumerate(results):
+        for b in range(pairs_per_step):
+            rows.append(torch.cat([fine[b], score[b][:, None], coarse[b].to(fine[b].dtype)], dim=1))
+            ids.append(torch.full((fine[b].shape[0],), (i * world + rank) * pairs_per_step + b, dtype=torch.int64,
+                                  device=fine[b].device))
+    if not rows:
+        return torch.zeros((0, 9)), torch.zeros((0,), dtype=torch.int64)
+    return torch.cat(rows), torch.cat(ids)
+
+
 def gather_matches(rows, pair_ids, group=None):
     """All-gather ragged per-rank results.
 

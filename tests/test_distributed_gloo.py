@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from patch2pix_amd.gather import gather_matches, shard_pairs
+from patch2pix_amd.gather import gather_matches, pack_results, shard_pairs
 
 
 def _free_port():
@@ -62,3 +62,40 @@ def test_single_process_is_identity():
     ids = torch.arange(4)
     a, b = gather_matches(rows, ids)
     assert a is rows and b is ids
+
+
+def _fake_step(rank, step, B):
+    """(fine, score, coarse) lists like Patch2Pix.fine_from_ticket returns, sizes depending on (rank, step, pair)."""
+    g = torch.Generator().manual_seed(1000 * rank + step)
+    n = [(3 * rank + 2 * step + b) % 4 for b in range(B)]
+    return ([torch.rand(k, 4, generator=g) for k in n], [torch.rand(k, generator=g) for k in n],
+            [torch.randint(0, 640, (k, 4), generator=g) for k in n])
+
+
+def _bench_worker(rank, world, port, steps, B, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    results = [_fake_step(rank, i, B) for i in range(steps)]
+    ret[rank] = gather_matches(*pack_results(results, rank, world, B))        # exactly bench.py's final exchange
+    dist.destroy_process_group()
+
+
+def test_bench_final_exchange_on_two_ranks():
+    """bench.py --gpus 2: every rank packs its steps with pack_results and the ranks exchange them with gather_matches;
+    the gathered set must hold every (rank, step, pair) result exactly once under its global pair id."""
+    world, steps, B = 2, 3, 2
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_bench_worker, args=(world, port, steps, B, ret), nprocs=world, join=True)
+    rows, ids = ret[0]
+    assert torch.equal(rows, ret[1][0]) and torch.equal(ids, ret[1][1]) and ids.dtype == torch.int64
+    total = 0
+    for r in range(world):
+        for i in range(steps):
+            fine, score, coarse = _fake_step(r, i, B)
+            for b in range(B):
+                got = rows[ids == (i * world + r) * B + b]
+                want = torch.cat([fine[b], score[b][:, None], coarse[b].float()], dim=1)
+                assert torch.equal(got, want)
+                total += want.shape[0]
+    assert rows.shape[0] == total and len(set(ids.tolist())) <= world * steps * B

@@ -825,3 +825,31 @@ def test_device_side_filter_path_equals_host_path(dev):
         for b in range(3):
             assert torch.equal(dcoarse[b], coarse[b]), (mutual, thres, b)
             assert torch.equal(dfine[b], fine[b]) and torch.equal(dscores[b], scores[b]), (mutual, thres, b)
+
+
+def test_graphed_matcher_equals_eager_path(dev):
+    """utils/eval/graphed.py: the device path captured as ONE hipGraph (pyramids in, matches out; and images in, with
+    the backbone inside the graph) replays to exactly what the eager calls return, for two different inputs per graph."""
+    from patch2pix_amd.utils.eval import model_helper
+    from patch2pix_amd.utils.eval.graphed import GraphedMatcher
+    net = model_helper.load_model(synthetic.make_checkpoint(0), lprint=lambda *a: None)
+    H, W = 128, 160
+    # (1) pyramids as the static inputs: bit-identical to the eager host-filter path
+    g = GraphedMatcher(net, H, W, with_backbone=False)
+    for seed in (910, 911):
+        p1, p2 = synthetic.make_correlated_pyramids(seed, H, W)
+        f1, f2 = [t[None].to(dev) for t in p1], [t[None].to(dev) for t in p2]
+        fine, scores, coarse = net.predict_fine_from_feats(f1, f2, ksize=2)
+        gfine, gscores, gcoarse = g(f1, f2)
+        assert torch.equal(gcoarse[0], coarse[0]) and torch.equal(gfine[0], fine[0]) and torch.equal(gscores[0], scores[0])
+    # (2) images as the static inputs, backbone inside the graph
+    g2 = GraphedMatcher(net, H, W, with_backbone=True)
+    for seed in (5, 6):
+        a, b = synthetic.make_image_pair(seed, H, W)
+        norm = lambda x: (torch.from_numpy(x).permute(2, 0, 1).float() / 255.0 - 0.45)[None].to(dev) / 0.225
+        ia, ib = norm(a), norm(b)
+        with torch.no_grad():
+            fine, scores, coarse = net.predict_fine(ia, ib, ksize=2)
+        gfine, gscores, gcoarse = g2(ia, ib)
+        assert torch.equal(gcoarse[0], coarse[0])
+        assert (gfine[0] - fine[0]).abs().max() <= COORD_TOL and (gscores[0] - scores[0]).abs().max() <= SCORE_TOL

@@ -49,6 +49,36 @@ def measure(net, H=480, W=640, pairs=4, reps=3, stream_pairs=32):
         torch.cuda.synchronize()
         out["stream_pairs_per_s"] = nres / (time.perf_counter() - t0)
         out["stream"] = "estimate_matches_stream(batch=8, workers=16)"
+    # single-pair latency, images already on the device: eager (host-side filter_coarse, ~700 launches) against the
+    # whole path -- backbone, coarse stage, device-side filter, both regressors -- replayed as one hipGraph
+    try:
+        from patch2pix_amd.utils.eval.graphed import GraphedMatcher
+        a, b = synthetic.make_image_pair(7, H, W)
+        norm = lambda x: ((torch.from_numpy(x).permute(2, 0, 1).float() / 255.0 - torch.tensor([0.485, 0.456, 0.406])[:, None, None])
+                          / torch.tensor([0.229, 0.224, 0.225])[:, None, None])[None].to(net.device)
+        ia, ib = norm(a), norm(b)
+        with torch.no_grad():
+            for _ in range(3):
+                net.predict_fine(ia, ib, ksize=2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                net.predict_fine(ia, ib, ksize=2)
+            torch.cuda.synchronize()
+            out["latency_ms_pair_eager"] = (time.perf_counter() - t0) / 10 * 1e3
+            g = GraphedMatcher(net, H, W).capture()
+            g.load(ia, ib)
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                g.replay()
+            torch.cuda.synchronize()
+            out["latency_ms_pair_hipgraph"] = (time.perf_counter() - t0) / 20 * 1e3
+            out["hipgraph_proposals"] = int(g.out[3][0])
+    except Exception as e:      # informational
+        out["latency_error"] = repr(e)
     im = torch.randn(2, 3, H, W, device=net.device)
     with torch.no_grad():
         for _ in range(3):
