@@ -277,6 +277,25 @@ def test_estimate_matches_golden(name, dev, tmp_path):
     mc, sc, cc = model_helper.estimate_matches(net, str(tmp_path / "1.png"), str(tmp_path / "2.png"), ksize=2,
                                                ncn_thres=0.0, eval_type="coarse", imsize=imsize)
     assert mc.shape[1] == 4 and np.array_equal(mc, cc)
+    # The strict form: the same entry point with the backbone evaluated on the CPU like in the golden run (identical
+    # pyramids on both sides; everything after the backbone stays on the HIP path).  Now every row must be there, in
+    # the reference's order, within 1e-3 px / 1e-5.
+    import copy
+    cpu_extract = copy.deepcopy(net.extract).to("cpu")
+    gpu_pyramid = net.extract.pyramid
+    net.extract.pyramid = lambda im: [f.to(dev) for f in cpu_extract.pyramid(im.cpu())]
+    try:
+        m, s, c = model_helper.estimate_matches(net, str(tmp_path / "1.png"), str(tmp_path / "2.png"), ksize=2,
+                                                io_thres=0.25, eval_type="fine", imsize=imsize)
+        mc, sc, cc = model_helper.estimate_matches(net, str(tmp_path / "1.png"), str(tmp_path / "2.png"), ksize=2,
+                                                   ncn_thres=0.0, eval_type="coarse", imsize=imsize)
+    finally:
+        net.extract.pyramid = gpu_pyramid
+    assert c.shape == g["fine_coarse"].shape and np.array_equal(c, g["fine_coarse"]), "coarse rows of the fine path differ"
+    scale = max(1.0, max(int(g["H"]), int(g["W"])) / float(imsize) * 1.1) if imsize else 1.0     # original-pixel factor
+    assert np.abs(m - g["fine_matches"]).max() <= COORD_TOL * scale and np.abs(s - g["fine_scores"]).max() <= SCORE_TOL
+    # coarse scores = 1 / sum(exp(x - max)) over 1200 cells of the consensus output: same bar as the other coarse tests
+    assert np.array_equal(mc, g["coarse_matches"]) and np.allclose(sc, g["coarse_scores"], rtol=1e-4, atol=0)
 
 
 def test_batched_launch_equals_per_pair(dev, ops, weights):
