@@ -208,6 +208,18 @@ __device__ __forceinline__ void split3(const f32x4 &xa, const f32x4 &xb, float s
 #define XPB() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
 #define XPP() __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
 #endif
+#ifdef XF_TURN4                         // experiment: four slabs per turn in conv2
+#define XPP2()
+#else
+#define XPP2() XPP()
+#endif
+#if defined(XF_CONV1_PAIR) && !defined(XF_NO_PINGPONG)   // experiment: conv1 halves aligned range against range (P beside C), no exclusive turns
+#define XPB_TURN(c)
+#define XPB_END(st) XPB()
+#else
+#define XPB_TURN(c) if (c) XPB()
+#define XPB_END(st) if (!(st)) XPB()
+#endif
 // (the MFMAs lead: the first ones issue as soon as the turn starts, the loads for later slabs follow in their shadow)
 #define XHSLAB(AC0, AC1, AN0, AN1, NP0, NP1, BC0, BC1, BN0, BN1, AH)                       \
     { XLOADP(AN0, NP0, HPL) XLOADP(AN1, NP1, HPL) XLOADB(BN0, AH) XLOADB(BN1, (AH) + 1)                                \
@@ -463,7 +475,7 @@ __global__ __launch_bounds__(NT, 2) void regress_x3_kernel(RegressArgs args) {
                         sc[t] = ok ? scale[img * 256 + pyc * 16 + pxc] : 0.f;
                     }
                     const unsigned char *a0 = smb + ab[0], *a1 = smb + ab[1];
-                    if (stagger) XPB()
+                    XPB_TURN(stagger)
 #ifdef XF_SKIP_P                        // timing experiments (wrong results): XF_SKIP_P / _C / _FOLD / _CONV2 drop one part
                     XWADV(8) (void)a0; (void)a1; (void)sc;
 #else
@@ -493,7 +505,7 @@ __global__ __launch_bounds__(NT, 2) void regress_x3_kernel(RegressArgs args) {
                     }
                     const unsigned char *q2 = smb + a2, *q3 = smb + a3;
                     f32x16 t0, t1;
-                    XPB()
+                    XPB_TURN(1)
 #ifdef XF_SKIP_C
                     t0 = acc00; t1 = acc01; XWADV(24) (void)q2; (void)q3;
 #else
@@ -513,7 +525,7 @@ __global__ __launch_bounds__(NT, 2) void regress_x3_kernel(RegressArgs args) {
                         XWADV(4)
                     }
 #endif
-                    XPB()
+                    XPB_TURN(1)
                     XT(5)
 #ifndef XF_SKIP_FOLD
                     // fold: acc[pixel][n] += scale[pixel] * T[cell row of the pixel][n]
@@ -544,7 +556,7 @@ __global__ __launch_bounds__(NT, 2) void regress_x3_kernel(RegressArgs args) {
 #else
                     acc00 += t0; acc01 += t1;
 #endif
-                    if (!stagger) XPB()
+                    XPB_END(stagger)
                     XT(6)
                 }
             }
@@ -661,14 +673,14 @@ __global__ __launch_bounds__(NT, 2) void regress_x3_kernel(RegressArgs args) {
                     // 8 slabs of 16 channels = 32 bytes per plane; slab j of a group of four loads the units of slab j + 3
                     XHSLAB(A00, A01, A10, A11, p0 + 32, p1 + 32, B0, B1, B6, B7, 6)
                     XHSLAB(A10, A11, A00, A01, p0 + 64, p1 + 64, B2, B3, B0, B1, 8)
-                    XPP()
+                    XPP2()
                     XHSLAB(A00, A01, A10, A11, p0 + 96, p1 + 96, B4, B5, B2, B3, 10)
                     XHSLAB(A10, A11, A00, A01, p0 + 128, p1 + 128, B6, B7, B4, B5, 12)
                     XPP()
                     XWADV(8)
                     XHSLAB(A00, A01, A10, A11, p0 + 160, p1 + 160, B0, B1, B6, B7, 6)
                     XHSLAB(A10, A11, A00, A01, p0 + 192, p1 + 192, B2, B3, B0, B1, 8)
-                    XPP()
+                    XPP2()
                     XHSLAB(A00, A01, A10, A11, p0 + 224, p1 + 224, B4, B5, B2, B3, 10)
                     XHSLAB(A10, A11, A00, A01, n0, n1, B6, B7, B4, B5, 12)
                     XPP()
