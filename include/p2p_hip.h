@@ -142,6 +142,16 @@ int p2p_coarse_matches_batch(const float *corr4d, const uint8_t *delta, int batc
 int p2p_filter_coarse_batch(const int64_t *matches, const float *scores, int batch, int n, float ncn_thres, int mutual,
                             int64_t *out_matches, float *out_scores, int *out_counts, p2p_stream_t stream);
 
+/* The tail of estimate_matches -- reference utils/eval/model_helper.py:92-109 -- for a batch with device-side counts:
+ * per item keep the rows with fine score > io_thres (all rows if none passes), in order, and scale refined and coarse
+ * coordinates to original-image pixels in float64.
+ *   fine [B,stride,4] fp32, scores [B,stride] fp32, coarse [B,stride,4] int64, counts [B] int32 (device; valid rows per
+ *   item, -1 passes through), scale [B,4] float64 (device; w1o/w1, h1o/h1, w2o/w2, h2o/h2)
+ *   -> out_matches [B,stride,4] f64, out_scores [B,stride] fp32, out_coarse [B,stride,4] f64, out_counts [B] int32.   */
+int p2p_match_tail_batch(const float *fine, const float *scores, const int64_t *coarse, const int *counts,
+                         const double *scale, int batch, int stride, float io_thres, double *out_matches,
+                         float *out_scores, double *out_coarse, int *out_counts, p2p_stream_t stream);
+
 /* ---- fine stage ------------------------------------------------------------------------------ */
 
 /* One image's feature pyramid levels feat_idx [0,1,2,3] (reference networks/resnet.py:138-157 with

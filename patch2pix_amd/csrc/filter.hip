@@ -134,9 +134,77 @@ __global__ __launch_bounds__(FT) void filter_coarse_kernel(FilterArgs a) {
     if (tid == 0) a.out_counts[item] = all ? nsel : npass;
 }
 
+// The tail of estimate_matches (utils/eval/model_helper.py:92-109) for a batch of items with device-side counts:
+// keep the rows whose fine score exceeds io_thres -- all rows if none does --, in order, and scale the refined and the
+// coarse coordinates to original-image pixels in float64 (scale = [w1o/w1, h1o/h1, w2o/w2, h2o/h2] per item).
+struct TailArgs {
+    const float *fine;                        // [B][stride][4]
+    const float *scores;                      // [B][stride]
+    const long long *coarse;                  // [B][stride][4]
+    const int *counts;                        // [B] valid rows per item (device); < 0 passes through as -1
+    const double *scale;                      // [B][4]
+    int stride;
+    float thres;
+    double *out_matches;                      // [B][stride][4]
+    float *out_scores;                        // [B][stride]
+    double *out_coarse;                       // [B][stride][4]
+    int *out_counts;                          // [B]
+};
+
+__global__ __launch_bounds__(FT) void match_tail_kernel(TailArgs a) {
+    __shared__ int wave_sums[FT / 64];
+    const int tid = threadIdx.x, item = blockIdx.x;
+    const int n = a.counts[item];
+    if (n < 0) {
+        if (tid == 0) a.out_counts[item] = -1;
+        return;
+    }
+    const float *fine = a.fine + (size_t)item * a.stride * 4;
+    const float *sc = a.scores + (size_t)item * a.stride;
+    const long long *co = a.coarse + (size_t)item * a.stride * 4;
+    double *om = a.out_matches + (size_t)item * a.stride * 4, *oc = a.out_coarse + (size_t)item * a.stride * 4;
+    float *os = a.out_scores + (size_t)item * a.stride;
+    const double s0 = a.scale[item * 4], s1 = a.scale[item * 4 + 1], s2 = a.scale[item * 4 + 2], s3 = a.scale[item * 4 + 3];
+    const int per = (n + FT - 1) / FT, j0 = min(tid * per, n), j1 = min(j0 + per, n);
+    int pass = 0;
+    for (int j = j0; j < j1; ++j) pass += sc[j] > a.thres;
+    int npass;
+    int at = block_exclusive_scan(pass, wave_sums, &npass);
+    const bool all = (npass == 0);
+    if (all) at = j0;
+    for (int j = j0; j < j1; ++j) {
+        const float s = sc[j];
+        if (all || s > a.thres) {
+            om[(size_t)at * 4 + 0] = s0 * (double)fine[(size_t)j * 4 + 0];
+            om[(size_t)at * 4 + 1] = s1 * (double)fine[(size_t)j * 4 + 1];
+            om[(size_t)at * 4 + 2] = s2 * (double)fine[(size_t)j * 4 + 2];
+            om[(size_t)at * 4 + 3] = s3 * (double)fine[(size_t)j * 4 + 3];
+            oc[(size_t)at * 4 + 0] = s0 * (double)co[(size_t)j * 4 + 0];
+            oc[(size_t)at * 4 + 1] = s1 * (double)co[(size_t)j * 4 + 1];
+            oc[(size_t)at * 4 + 2] = s2 * (double)co[(size_t)j * 4 + 2];
+            oc[(size_t)at * 4 + 3] = s3 * (double)co[(size_t)j * 4 + 3];
+            os[at] = s;
+            ++at;
+        }
+    }
+    if (tid == 0) a.out_counts[item] = all ? n : npass;
+}
+
 }  // namespace p2p
 
 using namespace p2p;
+
+extern "C" int p2p_match_tail_batch(const float *fine, const float *scores, const int64_t *coarse, const int *counts,
+                                    const double *scale, int batch, int stride, float io_thres, double *out_matches,
+                                    float *out_scores, double *out_coarse, int *out_counts, p2p_stream_t stream) {
+    P2P_REQUIRE(fine && scores && coarse && counts && scale && out_matches && out_scores && out_coarse && out_counts,
+                P2P_EINVAL, "p2p_match_tail: null argument");
+    P2P_REQUIRE(batch >= 1 && batch <= 65535 && stride >= 1, P2P_EINVAL, "p2p_match_tail: bad sizes");
+    TailArgs a{fine, scores, (const long long *)coarse, counts, scale, stride, io_thres, out_matches, out_scores, out_coarse,
+               out_counts};
+    hipLaunchKernelGGL(match_tail_kernel, dim3(batch), dim3(FT), 0, (hipStream_t)stream, a);
+    return check_launch("match_tail_kernel");
+}
 
 extern "C" int p2p_filter_coarse_batch(const int64_t *matches, const float *scores, int batch, int n, float ncn_thres,
                                        int mutual, int64_t *out_matches, float *out_scores, int *out_counts,

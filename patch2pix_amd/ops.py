@@ -216,6 +216,31 @@ def filter_coarse_batch(matches, scores, ncn_thres=0.0, mutual=True):
     return out_m, out_s, counts
 
 
+def match_tail_batch(fine, scores, coarse, counts, scale, io_thres):
+    """The tail of estimate_matches (utils/eval/model_helper.py:92-109) on the device for padded batch outputs:
+    fine [B,n,4] fp32, scores [B,n] fp32, coarse [B,n,4] int64, counts int32 [B] (device), scale [B,4] float64 ->
+    (matches [B,n,4] float64, scores [B,n] fp32, coarse [B,n,4] float64, counts int32 [B]); rows with score > io_thres
+    are kept in order (all rows if none passes) and scaled to original-image pixels."""
+    if fine.dtype != torch.float32 or coarse.dtype != torch.int64 or counts.dtype != torch.int32 or not fine.is_cuda:
+        raise TypeError("match_tail_batch: fine fp32, coarse int64, counts int32 on the GPU expected")
+    fine, scores, coarse = fine.contiguous(), _f32c(scores, "scores"), coarse.contiguous()
+    nb, n, _ = fine.shape
+    dev = fine.device
+    scale = torch.as_tensor(scale, dtype=torch.float64).reshape(nb, 4).to(dev)
+    out_m = torch.empty((nb, n, 4), dtype=torch.float64, device=dev)
+    out_c = torch.empty((nb, n, 4), dtype=torch.float64, device=dev)
+    out_s = torch.empty((nb, n), dtype=torch.float32, device=dev)
+    out_n = torch.empty((nb,), dtype=torch.int32, device=dev)
+    if nb and n:
+        with torch.cuda.device(dev):
+            _lib.check(_lib.p2p_match_tail_batch(fine.data_ptr(), scores.data_ptr(), coarse.data_ptr(), counts.data_ptr(),
+                                                 scale.data_ptr(), nb, n, float(io_thres), out_m.data_ptr(), out_s.data_ptr(),
+                                                 out_c.data_ptr(), out_n.data_ptr(), _stream()), "p2p_match_tail_batch")
+    else:
+        out_n.zero_()
+    return out_m, out_s, out_c, out_n
+
+
 def regress_batch_dev(reg1, reg2, pyrs1, pyrs2, proposals, counts, want_raw=False):
     """regress_batch with the proposal counts in device memory: proposals [B,stride,4] (int64 or float32), counts int32
     [B] on the GPU; every output is padded to [B,stride,...], rows beyond counts[b] are left uninitialised."""

@@ -20,6 +20,7 @@ import torch
 from ..common.setup_helper import load_weights
 from ..datasets.preprocess import load_im_flexible, load_im_tensor
 from ...networks.patch2pix import Patch2Pix
+from ... import ops
 
 _SILENT = lambda *a, **k: None
 
@@ -122,6 +123,21 @@ def estimate_matches(net, im1, im2, ksize=2, ncn_thres=0.0, mutual=True, io_thre
     if confident.size:
         refined, confidence, proposals = refined[confident], confidence[confident], proposals[confident]
     return to_original * refined, confidence, to_original * proposals
+
+
+def estimate_matches_device(net, im1, im2, ksize=2, ncn_thres=0.0, mutual=True, io_thres=0.25, imsize=None):
+    """estimate_matches(eval_type='fine') with NOTHING between the image tensors and the result on the host
+    (non-reference entry point): coarse stage, filter_coarse, both regressors and the io_thres / scaling tail of
+    model_helper.py:92-109 all run on the device; one device-to-host copy at the end.  Same return triple."""
+    t1, t2, to_original = _load_pair(net, im1, im2, ksize, imsize)
+    with torch.no_grad():
+        fine, scores, coarse, counts = net.predict_fine_device(net.extract.pyramid(t1), net.extract.pyramid(t2), ksize=ksize,
+                                                               ncn_thres=ncn_thres, mutual=mutual)
+        m, s, c, n = ops.match_tail_batch(fine, scores, coarse, counts, to_original, io_thres)
+    k = int(n[0])
+    if k < 0:          # a coordinate outside the device filter's packed key: the reference path
+        return estimate_matches(net, im1, im2, ksize, ncn_thres, mutual, io_thres, "fine", imsize)
+    return _host(m[0, :k]), _host(s[0, :k]), _host(c[0, :k])
 
 
 def refine_matches(im1_path, im2_path, net, coarse_matcher, io_thres=0.0, imsize=None, coarse_only=False):

@@ -129,3 +129,16 @@ def filter_coarse_batch(emu, matches, scores, thres, mutual):
         c = int(cnt[b])
         out.append(None if c < 0 else (om[b, :c].clone(), osc[b, :c].clone()))
     return out
+
+
+def match_tail_batch(emu, fine, scores, coarse, counts, scale, io_thres):
+    """p2p_match_tail_batch on CPU tensors -> list of (matches f64, scores f32, coarse f64) per item (None for count -1)."""
+    fine, scores, coarse = fine.contiguous(), scores.contiguous(), coarse.contiguous()
+    counts, scale = counts.to(torch.int32).contiguous(), scale.to(torch.float64).contiguous()
+    nb, n, _ = fine.shape
+    om, oc = torch.empty((nb, n, 4), dtype=torch.float64), torch.empty((nb, n, 4), dtype=torch.float64)
+    osc, on = torch.empty((nb, n), dtype=torch.float32), torch.empty((nb,), dtype=torch.int32)
+    check(emu, emu.p2p_match_tail_batch(ptr(fine), ptr(scores), ptr(coarse), ptr(counts), ptr(scale), nb, n, float(io_thres),
+                                        ptr(om), ptr(osc), ptr(oc), ptr(on), None), "p2p_match_tail_batch")
+    return [None if int(on[b]) < 0 else (om[b, :int(on[b])].clone(), osc[b, :int(on[b])].clone(), oc[b, :int(on[b])].clone())
+            for b in range(nb)]

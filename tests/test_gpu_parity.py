@@ -872,3 +872,21 @@ def test_graphed_matcher_equals_eager_path(dev):
         gfine, gscores, gcoarse = g2(ia, ib)
         assert torch.equal(gcoarse[0], coarse[0])
         assert (gfine[0] - fine[0]).abs().max() <= COORD_TOL and (gscores[0] - scores[0]).abs().max() <= SCORE_TOL
+
+
+@pytest.mark.parametrize("io_thres", [0.25, 0.99])
+def test_estimate_matches_device_equals_host_tail(io_thres, dev, tmp_path):
+    """model_helper.estimate_matches_device (filter_coarse, regressors AND the io_thres / scaling tail on the device, one
+    copy back) returns exactly the triple of estimate_matches; io_thres 0.99 exercises the keep-everything fall-back."""
+    from PIL import Image
+    from patch2pix_amd.utils.eval import model_helper
+    im1, im2 = synthetic.make_image_pair(21, 300, 420)
+    Image.fromarray(im1).save(tmp_path / "1.png")
+    Image.fromarray(im2).save(tmp_path / "2.png")
+    net = _model(dev)
+    a = model_helper.estimate_matches(net, str(tmp_path / "1.png"), str(tmp_path / "2.png"), ksize=2, io_thres=io_thres, imsize=256)
+    b = model_helper.estimate_matches_device(net, str(tmp_path / "1.png"), str(tmp_path / "2.png"), ksize=2, io_thres=io_thres,
+                                             imsize=256)
+    assert a[0].shape[0] > 0
+    for x, y in zip(a, b):
+        assert x.dtype == y.dtype and np.array_equal(x, y)

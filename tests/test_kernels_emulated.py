@@ -296,3 +296,29 @@ def test_regress_with_device_counts(emu, sd):
             assert torch.equal(m1[used], single["matches1"]) and torch.equal(m2[used], single["matches2"])
             assert torch.equal(p1[used], single["probs1"]) and torch.equal(p2[used], single["probs2"])
         assert bool((m1[rest] == mark).all() and (m2[rest] == mark).all() and (p2[rest] == mark).all())
+
+
+def test_match_tail_against_reference_semantics(emu):
+    """p2p_match_tail_batch == the numpy tail of estimate_matches (utils/eval/model_helper.py:92-109): rows with score >
+    io_thres in order, everything if none passes, float64 scaling; counts of -1 pass through."""
+    import numpy as np
+    g = torch.Generator().manual_seed(5)
+    B, n = 4, 700
+    fine = torch.rand(B, n, 4, generator=g) * 600
+    scores = torch.rand(B, n, generator=g)
+    scores[2] *= 0.2                                   # item 2: nothing passes 0.25 -> everything is kept
+    coarse = torch.randint(0, 640, (B, n, 4), generator=g)
+    counts = torch.tensor([700, 123, 300, -1], dtype=torch.int32)
+    scale = torch.tensor([[1.0, 1.0, 1.0, 1.0], [1.6, 1.5, 2.0, 2.25], [1.0 / 3.0, 1.7, 1.1, 1.3], [1, 1, 1, 1]], dtype=torch.float64)
+    got = emu_lib.match_tail_batch(emu, fine, scores, coarse, counts, scale, 0.25)
+    assert got[3] is None
+    for b in range(3):
+        c = int(counts[b])
+        f, s, co = fine[b, :c].numpy(), scores[b, :c].numpy(), coarse[b, :c].numpy()
+        pos = np.where(s > 0.25)[0]
+        if len(pos) > 0:
+            f, s, co = f[pos], s[pos], co[pos]
+        up = scale[b].numpy()[None]
+        assert np.array_equal(got[b][0].numpy(), up * f) and np.array_equal(got[b][1].numpy(), s)
+        assert np.array_equal(got[b][2].numpy(), up * co) and got[b][0].dtype == torch.float64
+    assert len(got[2][1]) == 300
