@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace p2p {
@@ -40,6 +41,9 @@ constexpr int KEY_NEG_INF = (int)0xff800000 ^ 0x7fffffff;
 // 1. L2 normalise + transpose to position-major with cell-major position order (modules.py:6)
 // ------------------------------------------------------------------------------------------------
 constexpr int PREP_P = 16;    // positions per work-group (300 groups at 60x80: fills the chip)
+// X3: write the normalised features as three bf16 planes [plane][pos'][C] (exact: v = p0 + p1 + p2) for
+// corr_pool_x3_kernel instead of fp32 [pos'][C]; the plane stride is hw * C elements.
+template <bool X3>
 __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ F, float *__restrict__ Fn, int C, int h,
                                                    int w, int k, size_t sF, size_t sFn) {
     F += blockIdx.z * sF;
@@ -82,7 +86,22 @@ __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ F, 
         if (pos >= hw) break;
         const int i = pos / w, j = pos - i * w;
         const int pp = ((i / k) * wc + (j / k)) * (k * k) + (i % k) * k + (j % k);
-        for (int c = tid; c < C; c += 256) Fn[(size_t)pp * C + c] = tile[c * (PREP_P + 1) + p] * inv[p];
+        for (int c = tid; c < C; c += 256) {
+            const float v = tile[c * (PREP_P + 1) + p] * inv[p];
+            if (!X3) {
+                Fn[(size_t)pp * C + c] = v;
+            } else {
+                unsigned short *d = (unsigned short *)Fn + (size_t)pp * C + c;
+                const size_t pl = (size_t)hw * C;
+                const unsigned short p0 = __builtin_bit_cast(unsigned short, (__bf16)v);
+                const float r1 = v - __uint_as_float((unsigned)p0 << 16);
+                const unsigned short p1 = __builtin_bit_cast(unsigned short, (__bf16)r1);
+                const float r2 = r1 - __uint_as_float((unsigned)p1 << 16);
+                d[0] = p0;
+                d[pl] = p1;
+                d[2 * pl] = __builtin_bit_cast(unsigned short, (__bf16)r2);
+            }
+        }
     }
 }
 
@@ -188,6 +207,135 @@ __global__ __launch_bounds__(256) void corr_pool_kernel(const float *__restrict_
                 }
             }
         }
+}
+
+// The same GEMM + pooling epilogue in fp32-equivalent arithmetic on the bf16 matrix cores (P2P_CORR_MODE=bf16x3, the
+// default): both operands arrive as three bf16 planes (prep_kernel<true>), a product is the six
+// v_mfma_f32_32x32x16_bf16 of order <= 2 (see regress_x3.hip), fp32 accumulation.  No VALU in the loop: per K = 16
+// slab and wave 12 ds_read_b128 and 24 MFMAs.  LDS: [A|B][plane][128 rows][32 K bf16 (+16 B pad)] = 60 KB.
+typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
+constexpr int CX_ROW = 32 * 2 + 16;          // bytes per LDS row: 80 = 5 x 16 (odd multiple: conflict-free ds_read_b128)
+constexpr int CX_PLANE = CT * CX_ROW;        // 10240
+constexpr int CX_MAT = 3 * CX_PLANE;         // 30720
+#define CXMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cbf16x8, (a)), __builtin_bit_cast(cbf16x8, (b)), (c), 0, 0, 0)
+
+template <int KS>
+__global__ __launch_bounds__(256) void corr_pool_x3_kernel(const unsigned short *__restrict__ A, const unsigned short *__restrict__ B,
+                                                           int nA, int nB, int C, float *__restrict__ P,
+                                                           uint8_t *__restrict__ delta, size_t sAB, size_t sP, size_t sDelta) {
+    A += blockIdx.z * sAB * 2;               // sAB is in 4-byte words
+    B += blockIdx.z * sAB * 2;
+    P += blockIdx.z * sP;
+    if (delta) delta += blockIdx.z * sDelta;
+    P2P_DYN_SHARED(unsigned char, cx);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int rowA0 = blockIdx.y * CT, rowB0 = blockIdx.x * CT;
+    const size_t plA = (size_t)nA * C, plB = (size_t)nB * C;       // plane strides in elements
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
+
+    // loader: per plane and matrix 128 rows x 64 B = 512 16-byte pieces: thread -> pieces tid and tid + 256
+    const int lrow = tid >> 2, lq = tid & 3;
+    for (int k0 = 0; k0 < C; k0 += 32) {
+        f32x4 va[3][2], vb[3][2];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = lrow + 64 * i;
+                const int ra = min(rowA0 + r, nA - 1), rb = min(rowB0 + r, nB - 1);
+                va[pl][i] = *(const f32x4 *)(A + pl * plA + (size_t)ra * C + k0 + lq * 8);
+                vb[pl][i] = *(const f32x4 *)(B + pl * plB + (size_t)rb * C + k0 + lq * 8);
+            }
+        __syncthreads();                     // the previous stage has been consumed
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = lrow + 64 * i;
+                *(f32x4 *)(cx + pl * CX_PLANE + r * CX_ROW + lq * 16) = va[pl][i];
+                *(f32x4 *)(cx + CX_MAT + pl * CX_PLANE + r * CX_ROW + lq * 16) = vb[pl][i];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {     // two slabs of 16 K
+            f32x4 a[2][3], b[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    a[i][pl] = *(const f32x4 *)(cx + pl * CX_PLANE + (wr * 64 + i * 32 + l31) * CX_ROW + kk * 32 + half * 16);
+                    b[i][pl] = *(const f32x4 *)(cx + CX_MAT + pl * CX_PLANE + (wc * 64 + i * 32 + l31) * CX_ROW + kk * 32 + half * 16);
+                }
+            // smallest terms first; the four accumulators rotate
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const int pa = (t == 0) ? 2 : (t == 1 || t == 3) ? 1 : 0;
+                const int pb = (t == 0 || t == 3 || t == 5) ? 0 : (t == 1 || t == 4) ? 1 : 2;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = CXMFMA(a[i][pa], b[j][pb], acc[i][j]);
+            }
+        }
+    }
+
+    // accumulator element r of lane: row = (r&3) + 8*(r>>2) + 4*half, col = l31 (the epilogue of corr_pool_kernel)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int tr = rowA0 + wr * 64 + i * 32, tc = rowB0 + wc * 64 + j * 32;
+            if (KS == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = tr + (r & 3) + 8 * (r >> 2) + 4 * half, col = tc + l31;
+                    if (row < nA && col < nB) P[(size_t)row * nB + col] = acc[i][j][r];
+                }
+            } else {
+                const int nAc = nA >> 2, nBc = nB >> 2;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float best = acc[i][j][4 * g];
+                    int s = 0;
+#pragma unroll
+                    for (int r = 1; r < 4; ++r) {
+                        const float v = acc[i][j][4 * g + r];
+                        if (v > best) { best = v; s = r; }
+                    }
+                    s = s * 4 + (lane & 3);
+#pragma unroll
+                    for (int m = 1; m <= 2; m <<= 1) {
+                        const float ov = __shfl_xor(best, m);
+                        const int os = __shfl_xor(s, m);
+                        if (ov > best || (ov == best && os < s)) { best = ov; s = os; }
+                    }
+                    if ((lane & 3) == 0) {
+                        const int crow = (tr >> 2) + 2 * g + half, ccol = (tc + l31) >> 2;
+                        if (crow < nAc && ccol < nBc) {
+                            P[(size_t)crow * nBc + ccol] = best;
+                            if (delta) delta[(size_t)crow * nBc + ccol] = (uint8_t)s;
+                        }
+                    }
+                }
+            }
+        }
+}
+
+// arithmetic of the correlation GEMM: bf16x3 (default, fp32-equivalent) or the exact fp32 MFMA (P2P_CORR_MODE=f32)
+static bool corr_x3() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = getenv("P2P_CORR_MODE");
+        mode = (e && !strcmp(e, "f32")) ? 0 : 1;
+    }
+    return mode == 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -694,8 +842,8 @@ static CoarseWs coarse_ws(int C, int hA, int wA, int hB, int wB, int k) {
     const size_t nAc = nA / (k * k), nBc = nB / (k * k);
     CoarseWs w;
     size_t off = 0;
-    w.fnA = off; off += al(nA * C * 4);
-    w.fnB = off; off += al(nB * C * 4);
+    w.fnA = off; off += al(nA * C * 6);      // fp32 [pos'][C] or three bf16 planes
+    w.fnB = off; off += al(nB * C * 6);
     w.P = off; off += al(nAc * nBc * 4);
     w.Y = off; off += al(nAc * nBc * 4);
     w.H1 = off; off += al(32 * nAc * nBc * 4);
@@ -785,16 +933,36 @@ extern "C" int p2p_coarse_forward_batch(const float *featA, const float *featB, 
         float *P = (float *)(base + ws.P), *Y = (float *)(base + ws.Y), *H1 = (float *)(base + ws.H1);
         int *rkey1 = (int *)(base + ws.keys), *ckey1 = rkey1 + nAc, *rkey2 = ckey1 + nBc, *ckey2 = rkey2 + nAc;
 
-        hipLaunchKernelGGL(prep_kernel, dim3(ceil_div(nA, PREP_P), 1, nz), dim3(256), 0, stream, fA, fnA, C, hA, wA, ksize,
-                           (size_t)C * nA, sWs);
-        hipLaunchKernelGGL(prep_kernel, dim3(ceil_div(nB, PREP_P), 1, nz), dim3(256), 0, stream, fB, fnB, C, hB, wB, ksize,
-                           (size_t)C * nB, sWs);
         const dim3 cgrid(ceil_div(nB, CT), ceil_div(nA, CT), nz);
-        if (ksize == 1)
-            hipLaunchKernelGGL(corr_pool_kernel<1>, cgrid, dim3(256), 0, stream, fnA, fnB, nA, nB, C, P, (uint8_t *)nullptr, sWs,
-                               sWs, (size_t)0);
-        else
-            hipLaunchKernelGGL(corr_pool_kernel<2>, cgrid, dim3(256), 0, stream, fnA, fnB, nA, nB, C, P, dout, sWs, sWs, nel);
+        if (corr_x3()) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                P2P_HIP_CHECK(hipFuncSetAttribute((const void *)corr_pool_x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CX_MAT));
+                P2P_HIP_CHECK(hipFuncSetAttribute((const void *)corr_pool_x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CX_MAT));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(prep_kernel<true>, dim3(ceil_div(nA, PREP_P), 1, nz), dim3(256), 0, stream, fA, fnA, C, hA, wA, ksize,
+                               (size_t)C * nA, sWs);
+            hipLaunchKernelGGL(prep_kernel<true>, dim3(ceil_div(nB, PREP_P), 1, nz), dim3(256), 0, stream, fB, fnB, C, hB, wB, ksize,
+                               (size_t)C * nB, sWs);
+            const unsigned short *pa = (const unsigned short *)fnA, *pb = (const unsigned short *)fnB;
+            if (ksize == 1)
+                hipLaunchKernelGGL(corr_pool_x3_kernel<1>, cgrid, dim3(256), 2 * CX_MAT, stream, pa, pb, nA, nB, C, P,
+                                   (uint8_t *)nullptr, sWs, sWs, (size_t)0);
+            else
+                hipLaunchKernelGGL(corr_pool_x3_kernel<2>, cgrid, dim3(256), 2 * CX_MAT, stream, pa, pb, nA, nB, C, P, dout, sWs,
+                                   sWs, nel);
+        } else {
+            hipLaunchKernelGGL(prep_kernel<false>, dim3(ceil_div(nA, PREP_P), 1, nz), dim3(256), 0, stream, fA, fnA, C, hA, wA, ksize,
+                               (size_t)C * nA, sWs);
+            hipLaunchKernelGGL(prep_kernel<false>, dim3(ceil_div(nB, PREP_P), 1, nz), dim3(256), 0, stream, fB, fnB, C, hB, wB, ksize,
+                               (size_t)C * nB, sWs);
+            if (ksize == 1)
+                hipLaunchKernelGGL(corr_pool_kernel<1>, cgrid, dim3(256), 0, stream, fnA, fnB, nA, nB, C, P, (uint8_t *)nullptr, sWs,
+                                   sWs, (size_t)0);
+            else
+                hipLaunchKernelGGL(corr_pool_kernel<2>, cgrid, dim3(256), 0, stream, fnA, fnB, nA, nB, C, P, dout, sWs, sWs, nel);
+        }
 
         const int nkeys = 2 * (nAc + nBc);
         hipLaunchKernelGGL(fill_keys_kernel, dim3(ceil_div(nkeys, 256), 1, nz), dim3(256), 0, stream, rkey1, nkeys, sWs);
