@@ -146,6 +146,10 @@ class Patch2Pix(nn.Module):
                     k.startswith(("ncn.", "regress_")) for k in weights_dict):
                 raise KeyError(f"checkpoint lacks hot-path weights: {missing[:5]} ...")
             self.load_state_dict(picked, strict=False)
+            if not any(k.startswith(("ncn.", "regress_")) for k in picked):
+                import warnings
+                warnings.warn("Patch2Pix: the checkpoint holds none of the ncn.* / regress_* weights; the matching path keeps "
+                              "its initial (zero) parameters and its matches are meaningless", RuntimeWarning)
         self._packed = None
 
     def load_state_dict(self, *args, **kwargs):
@@ -270,22 +274,34 @@ class Patch2Pix(nn.Module):
         key = (tuple(matches_.shape), self._pin_turn)
         self._pin_turn = (self._pin_turn + 1) % 4
         if key not in self._pinned:
-            self._pinned[key] = (torch.empty(matches_.shape, dtype=matches_.dtype, pin_memory=True),
-                                 torch.empty(score_.shape, dtype=score_.dtype, pin_memory=True))
-        host_m, host_s = self._pinned[key]
+            self._pinned[key] = [torch.empty(matches_.shape, dtype=matches_.dtype, pin_memory=True),
+                                 torch.empty(score_.shape, dtype=score_.dtype, pin_memory=True), None]
+        slot = self._pinned[key]
+        if slot[2] is not None and not slot[2].get("consumed", False):
+            # a fifth ticket of this shape while the first is still pending: its staging buffers are taken over, the
+            # old ticket falls back to its own device-to-host copy when (if) it is consumed
+            slot[2]["done"].synchronize()
+            slot[2]["stale"] = True
+        host_m, host_s = slot[0], slot[1]
+        # the tensors are produced on the main stream and read on the copy stream: keep the allocator from recycling them
+        matches_.record_stream(self._copy_stream)
+        score_.record_stream(self._copy_stream)
         with torch.cuda.stream(self._copy_stream):
             self._copy_stream.wait_event(ready)
             host_m.copy_(matches_, non_blocking=True)
             host_s.copy_(score_, non_blocking=True)
             done = torch.cuda.Event()
             done.record(self._copy_stream)
-        return dict(feats1=feats1, feats2=feats2, matches=matches_, scores=score_, host=(host_m, host_s), done=done)
+        ticket = dict(feats1=feats1, feats2=feats2, matches=matches_, scores=score_, host=(host_m, host_s), done=done)
+        slot[2] = ticket
+        return ticket
 
     def fine_from_ticket(self, ticket, ncn_thres=0.0, mutual=True, return_all=False, ptmax=None):
         ticket["done"].synchronize()
         host_m, host_s = ticket["host"]
         coarse_matches, match_scores = filter_coarse(ticket["matches"], ticket["scores"], ncn_thres, mutual, ptmax=ptmax,
-                                                     host_copy=(host_m.numpy(), host_s.numpy()))
+                                                     host_copy=None if ticket.get("stale") else (host_m.numpy(), host_s.numpy()))
+        ticket["consumed"] = True          # its pinned staging slot may be reused
         coarse_matches = self.shift_to_anchors(coarse_matches)
         fine, fine_scores, mid, mid_scores = self._fine_chain(ticket["feats1"], ticket["feats2"], coarse_matches)
         if return_all:

@@ -63,11 +63,12 @@ def filter_coarse(coarse_matches, match_scores, ncn_thres=0.0, mutual=True, ptma
     if device.type == "cuda":
         # through recycled pinned buffers: a copy from pageable memory would block the host until the stream
         # has drained, i.e. idle the GPU while the next launch is being prepared
-        pin_r, pin_s = _pinned(rows_np.shape[0])
+        pin_r, pin_s, done = _pinned(rows_np.shape[0])
         pin_r[:rows_np.shape[0]].copy_(torch.from_numpy(rows_np))
         pin_s[:rows_np.shape[0]].copy_(torch.from_numpy(scores_np))
         all_rows = pin_r[:rows_np.shape[0]].to(device, non_blocking=True)
         all_scores = pin_s[:rows_np.shape[0]].to(device, non_blocking=True)
+        done.record(torch.cuda.current_stream(device))      # the slot is reusable once this upload has run
     else:
         all_rows, all_scores = torch.from_numpy(rows_np), torch.from_numpy(scores_np)
     return list(torch.split(all_rows, counts)), list(torch.split(all_scores, counts))
@@ -77,7 +78,9 @@ _pin_ring, _pin_turn = [], [0]
 
 
 def _pinned(n):
-    """A (rows int64 [cap,4], scores f32 [cap]) pair of pinned staging buffers from a ring of 8."""
+    """(rows int64 [cap,4], scores f32 [cap], event) -- pinned staging buffers from a ring of 8.  The event is recorded
+    by the caller after its asynchronous upload; a slot is handed out again only after that upload has completed, so a
+    host that runs more than 8 uploads ahead of the stream waits here instead of overwriting a buffer still being read."""
     if len(_pin_ring) < 8:
         _pin_ring.append(None)
     slot = _pin_turn[0] % 8
@@ -85,8 +88,11 @@ def _pinned(n):
     if slot >= len(_pin_ring):
         _pin_ring.extend([None] * (slot + 1 - len(_pin_ring)))
     buf = _pin_ring[slot]
+    if buf is not None:
+        buf[2].synchronize()
     if buf is None or buf[0].shape[0] < n:
         cap = max(1024, 1 << (max(n, 1) - 1).bit_length())
-        buf = (torch.empty((cap, 4), dtype=torch.int64).pin_memory(), torch.empty((cap,), dtype=torch.float32).pin_memory())
+        buf = (torch.empty((cap, 4), dtype=torch.int64).pin_memory(), torch.empty((cap,), dtype=torch.float32).pin_memory(),
+               torch.cuda.Event())
         _pin_ring[slot] = buf
     return buf
