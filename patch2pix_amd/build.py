@@ -8,13 +8,33 @@ SOURCES = ["api.hip", "coarse.hip", "filter.hip", "regress.hip", "regress_split.
 LIB = os.path.join(CSRC, "libp2p_hip.so")
 
 
+STAMP = LIB + ".srchash"       # hash of the sources the library was built from (travels with the .so, git-ignored)
+
+
+def _deps():
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    deps.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "p2p_hip.h"))
+    return deps
+
+
+def source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for d in _deps():
+        h.update(os.path.basename(d).encode())
+        h.update(open(d, "rb").read())
+    return h.hexdigest()
+
+
 def _stale():
+    """By content, not by time stamp: a copied or checked-out tree does not keep mtimes, and a library older than the
+    sources next to it must never be picked up silently."""
     if not os.path.exists(LIB):
         return True
+    if os.path.exists(STAMP):
+        return open(STAMP).read().strip() != source_hash()
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
-    deps.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "p2p_hip.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in _deps())
 
 
 def _resource_report(text):
@@ -66,6 +86,8 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(source_hash())
     return LIB
 
 
