@@ -904,3 +904,30 @@ def test_estimate_matches_device_equals_host_tail(io_thres, dev, tmp_path):
     assert a[0].shape[0] > 0
     for x, y in zip(a, b):
         assert x.dtype == y.dtype and np.array_equal(x, y)
+
+
+def test_stream_against_reference_golden(dev, tmp_path):
+    """estimate_matches_stream (loader threads, batched backbone, shared launches) against the REFERENCE's recorded
+    estimate_matches output, not against this implementation's per-pair calls: the golden pair three times in one batch,
+    backbone on the CPU like in the golden run -> the reference's rows in order, 1e-3 px / 1e-5."""
+    import copy
+    from PIL import Image
+    from patch2pix_amd.utils.eval.stream import estimate_matches_stream
+    g = gu.load("estimate_matches_240x320")
+    im1, im2 = synthetic.make_image_pair(int(g["seed"]), int(g["H"]), int(g["W"]))
+    Image.fromarray(im1).save(tmp_path / "1.png")
+    Image.fromarray(im2).save(tmp_path / "2.png")
+    net = _model(dev)
+    cpu_extract = copy.deepcopy(net.extract).to("cpu")
+    gpu_pyramid = net.extract.pyramid
+    net.extract.pyramid = lambda im: [f.to(dev) for f in cpu_extract.pyramid(im.cpu())]
+    try:
+        out = list(estimate_matches_stream(net, [(str(tmp_path / "1.png"), str(tmp_path / "2.png"))] * 3, ksize=2, io_thres=0.25,
+                                           batch=3, workers=2))
+    finally:
+        net.extract.pyramid = gpu_pyramid
+    assert len(out) == 3
+    for m, s, c in out:
+        assert m.dtype == np.float64 and s.dtype == np.float32 and c.dtype == np.float64
+        assert np.array_equal(c, g["fine_coarse"])
+        assert np.abs(m - g["fine_matches"]).max() <= COORD_TOL and np.abs(s - g["fine_scores"]).max() <= SCORE_TOL
