@@ -11,8 +11,9 @@
 // (tools/split_check.py, tests/test_gpu_parity.py).  Cost: 6 bf16 MFMA passes per unit of K instead of 32 fp32
 // ones -> 2.65x the fp32-MFMA ceiling.
 //
-// The kernel is limited by the energy of what it issues (measured: wall time follows the MFMA count and the
-// VALU count; the shader clock sits at 1.8 GHz under it), so it is organised to issue as little as possible:
+// The kernel runs at the package power limit (measured: 1.32 kW, shader clock ~1.95 GHz; with all-zero weights the same
+// instruction stream runs at 2.4 GHz), so it is organised to issue as little as possible -- and so that the two waves
+// of a SIMD never issue MFMAs at the same time (profiles/r02_ablation_log.txt):
 //   * conv1, levels 2 and 3 of the patch (192 of 259 channels).  They are nearest-neighbour up-samplings (4x4 /
 //     8x8 pixels per cell) and a level-3 cell is determined by the level-2 cell, so the 64 output pixels of a
 //     tap touch <= 25 distinct (level-2 cell, level-3 parent) rows.  Their K-range is therefore multiplied ONCE
@@ -26,8 +27,11 @@
 //     wave = 72 times).  Three planes of H are 196 KB, so conv2 runs in four K-chunks of 128 input channels: the
 //     planes of one chunk (52 KB) are in LDS, the other chunks wait as fp32 (3 x 33 KB) and are converted by the
 //     whole work-group between chunks.  The conv2 loop has no VALU work at all.
-//   * weights are pre-split at load time: unit = (slab of 16 K, n-tile) = 3 planes x 1 KiB per wave, stream order
-//     [slab][n-tile], prefetched one slab ahead through a ring of four register buffers.
+//   * weights are pre-split at load time: unit = (slab of 16 K, n-tile) = 3 planes x 1 KiB per wave, stream order =
+//     consumption order per wave, addressed as scalar base + 16 * lane (one VGPR for the whole stream), prefetched one
+//     slab ahead through a ring of four register buffers in conv1 and three slabs ahead through eight in conv2.
+//   * the halves of the work-group (waves 0-3 / 4-7; wave w shares its SIMD with wave w + 4) take turns on the matrix
+//     pipe between bare s_barriers: two MFMA-dense waves on one SIMD got 57 % of the pipe, one wave alone 85 %.
 #include "regress_common.h"
 
 #include <vector>
@@ -40,7 +44,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---- LDS layout (bytes) --------------------------------------------------------------------------
 // conv1 phase, per image: level 1 as fp32 [81 cells][64 ch (+16 B pad)]; levels 2 and 3 as three bf16 planes
-// [plane][25 cells][64 ch (+16 B)] and [plane][9 cells][128 ch (+16 B)].  Then level 0 raw [img][3][256] and one
+// [plane][25 cells + a zero cell][64 ch (+16 B)] and [plane][9 cells + a zero cell][128 ch (+16 B)].  Then level 0 raw [img][3][256] and one
 // shared region that is, in turn: the fp32 copy of levels 2/3 the scale pass reads; the pre-scaled level-0 im2col
 // block A0[64 px][64 K fp32 (+16 B)] (K = img*32 + tap*3 + c, 27 real per image); the per-wave fold buffers
 // T[8 waves][28 cell rows][64 n] fp32.  Then the fold table [img][17][17] of {scale, T row offset} (row/column 0 =
@@ -51,15 +55,15 @@ constexpr int YST2 = 64 * 2 + 16, YNC2 = 25, YPL2 = (YNC2 + 1) * YST2;  // level
 constexpr int YST3 = 128 * 2 + 16, YNC3 = 9, YPL3 = (YNC3 + 1) * YST3;  // level 3
 constexpr int XOFF1 = 0;
 constexpr int YOFF2 = XOFF1 + XNC1 * XST1;                        // 22032
-constexpr int YOFF3 = YOFF2 + 3 * YPL2;                           // 32832
-constexpr int XIMG = YOFF3 + 3 * YPL3;                            // 40176
+constexpr int YOFF3 = YOFF2 + 3 * YPL2;                           // 33264
+constexpr int XIMG = YOFF3 + 3 * YPL3;                            // 41424
 constexpr int XRAW0 = 2 * XIMG;                                   // float [2][3][256]
-constexpr int XSHARED = XRAW0 + 2 * 3 * 256 * 4;                  // 86496
+constexpr int XSHARED = XRAW0 + 2 * 3 * 256 * 4;                  // 88992
 constexpr int XTMP2ST = 64 * 4 + 16, XTMP3ST = 128 * 4 + 16;      // fp32 copy of levels 2/3: [25][272] then [9][528]
 constexpr int XTMP3 = YNC2 * XTMP2ST, XTMPIMG = XTMP3 + YNC3 * XTMP3ST;
 constexpr int XA0ST = 64 * 4 + 16;
 constexpr int XTROWS = 28, XTROW = 64 * 4, XTW = XTROWS * XTROW;  // fold buffer of one wave
-constexpr int XTAB = XSHARED + 8 * XTW;                           // 143840
+constexpr int XTAB = XSHARED + 8 * XTW;                           // 146336
 constexpr int XTABIMG = 17 * 17 * 8;
 constexpr int XSM_SCALE = XTAB + 2 * XTABIMG + 16;                // float [2][256]
 constexpr int XCONV1B = XSM_SCALE + 512 * 4;
