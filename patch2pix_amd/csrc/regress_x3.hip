@@ -194,19 +194,9 @@ __device__ __forceinline__ void split3(const f32x4 &xa, const f32x4 &xb, float s
 #define XPRO(P0, P1, SC0) { XLOADR(R0, P0) XLOADR(R1, P1) split3(R0[0], R0[1], (SC0), S0[0], S0[1], S0[2]); }
 
 // ---- slabs whose A operand was split beforehand ------------------------------------------------------
-#ifdef XC_SPREAD                        // experiment: cell slabs with one load behind every MFMA
-#define XLPIPE(NDS, NMFMA)                                                               \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                \
-    _Pragma("unroll") for (int g_ = 0; g_ < 3; ++g_) {                                                               \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }       \
-    _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                                                               \
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }       \
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-#else
 #define XLPIPE(NDS, NMFMA)                                                               \
     __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0); __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);           \
     __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
-#endif
 // conv1, levels 2 + 3: one m-tile of cell rows -> T0/T1.  SC = planes of this slab, SN <- planes of the next (NP, NPL).
 #define XCSLAB(HALF, SC, SN, NP, NPL, BC0, BC1, BN0, BN1, AH)                             \
     { XLOADP(SN, NP, NPL) XLOADB(BN0, AH) XLOADB(BN1, (AH) + 1)                                                       \
@@ -235,13 +225,8 @@ __device__ __forceinline__ void split3(const f32x4 &xa, const f32x4 &xb, float s
 #define XPB_END(st) if (!(st)) XPB()
 #endif
 // (the MFMAs lead: the first ones issue as soon as the turn starts, the loads for later slabs follow in their shadow)
-#if defined(XH_SPREAD2)                 // experiment: one load behind every second MFMA
-#define XHPIPE()                                                                         \
-    _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                                                               \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }       \
-    _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                                                               \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
-#elif !defined(XH_BURST)                // one load behind every MFMA (measured 2.7 % faster than two bursts of six: XH_BURST)
+#ifndef XH_BURST                        // one load behind every MFMA: 2-3 % faster than two bursts of six at the head (XH_BURST);
+                                        // global loads first, alternating LDS/global loads, one load per two MFMAs: no better
 #define XHPIPE()                                                                         \
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                                \
     _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                                                               \
