@@ -217,12 +217,36 @@ __device__ __forceinline__ void split3(const f32x4 &xa, const f32x4 &xb, float s
 #else
 #define XPP2() XPP()
 #endif
-#if defined(XF_CONV1_PAIR) && !defined(XF_NO_PINGPONG)   // experiment: conv1 halves aligned range against range (P beside C), no exclusive turns
-#define XPB_TURN(c)
-#define XPB_END(st) XPB()
+// conv1 barrier protocol per step (see the loop): P0 before / P1 after the pixel range, C0 before / C1 after the cell
+// range, F after the fold.  Shipped: exclusive turns with staggered halves (waves 0-3: P | - | C | F, waves 4-7: - | C | F | P).
+#if defined(XF_NO_PINGPONG)
+#define XSTAGGER(g) (g)
+#define XPB_P0(st)
+#define XPB_P1()
+#define XPB_C0(g)
+#define XPB_C1(g)
+#define XPB_F(st, g)
+#elif defined(XF_CONV1_PAIR)            // experiment: halves aligned range against range (P beside C): worse
+#define XSTAGGER(g) (g)
+#define XPB_P0(st)
+#define XPB_P1() XPB()
+#define XPB_C0(g)
+#define XPB_C1(g)
+#define XPB_F(st, g) XPB()
+#elif defined(XF_PPAR)                  // experiment: both halves run the pixel range together, then take turns on the cell range
+#define XSTAGGER(g) 0
+#define XPB_P0(st)
+#define XPB_P1() XPB()
+#define XPB_C0(g) if (g) XPB()
+#define XPB_C1(g) XPB()
+#define XPB_F(st, g) if (!(g)) XPB()
 #else
-#define XPB_TURN(c) if (c) XPB()
-#define XPB_END(st) if (!(st)) XPB()
+#define XSTAGGER(g) (g)
+#define XPB_P0(st) if (st) XPB()
+#define XPB_P1() XPB()
+#define XPB_C0(g) XPB()
+#define XPB_C1(g) XPB()
+#define XPB_F(st, g) if (!(st)) XPB()
 #endif
 // (the MFMAs lead: the first ones issue as soon as the turn starts, the loads for later slabs follow in their shadow)
 #ifndef XH_BURST                        // one load behind every MFMA: 2-3 % faster than two bursts of six at the head (XH_BURST);
@@ -470,7 +494,7 @@ __global__ __launch_bounds__(NT, 2) void regress_x3_kernel(RegressArgs args) {
             // its fold.  In loop form: iteration it does P(it - stagger) then C(it) F(it).
             // The two halves also take turns on the matrix pipe (see XPP): per step, waves 0-3 run P | - | C | F and
             // waves 4-7 - | C | F | P between the same four barriers, so a fold always sits beside the partner's MFMAs.
-            const int stagger = wave >> 2;
+            const int stagger = XSTAGGER(wave >> 2), grp = wave >> 2; (void)grp;
 #pragma unroll 1
             for (int it = 0; it < 18 + stagger; ++it) {
                 const int pi = it - stagger;
@@ -492,7 +516,7 @@ __global__ __launch_bounds__(NT, 2) void regress_x3_kernel(RegressArgs args) {
                         sc[t] = ok ? scale[img * 256 + pyc * 16 + pxc] : 0.f;
                     }
                     const unsigned char *a0 = smb + ab[0], *a1 = smb + ab[1];
-                    XPB_TURN(stagger)
+                    XPB_P0(stagger)
 #ifdef XF_SKIP_P                        // timing experiments (wrong results): XF_SKIP_P / _C / _FOLD / _CONV2 drop one part
                     XWADV(8) (void)a0; (void)a1; (void)sc;
 #else
@@ -502,7 +526,7 @@ __global__ __launch_bounds__(NT, 2) void regress_x3_kernel(RegressArgs args) {
                     XSLABEND(sc[1], B2, B3, B0, B1, 4)
                     XWADV(4)
 #endif
-                    XPB()
+                    XPB_P1()
                     XT(4)
                 }
                 if (it < 18) {      // ---- C(it), F(it): levels 2 (64 ch) + 3 (128 ch), cell rows, pre-split planes
@@ -522,7 +546,7 @@ __global__ __launch_bounds__(NT, 2) void regress_x3_kernel(RegressArgs args) {
                     }
                     const unsigned char *q2 = smb + a2, *q3 = smb + a3;
                     f32x16 t0, t1;
-                    XPB_TURN(1)
+                    XPB_C0(grp)
 #ifdef XF_SKIP_C
                     t0 = acc00; t1 = acc01; XWADV(24) (void)q2; (void)q3;
 #else
@@ -542,7 +566,7 @@ __global__ __launch_bounds__(NT, 2) void regress_x3_kernel(RegressArgs args) {
                         XWADV(4)
                     }
 #endif
-                    XPB_TURN(1)
+                    XPB_C1(grp)
                     XT(5)
 #ifndef XF_SKIP_FOLD
                     // fold: acc[pixel][n] += scale[pixel] * T[cell row of the pixel][n]
@@ -573,7 +597,7 @@ __global__ __launch_bounds__(NT, 2) void regress_x3_kernel(RegressArgs args) {
 #else
                     acc00 += t0; acc01 += t1;
 #endif
-                    XPB_END(stagger)
+                    XPB_F(stagger, grp)
                     XT(6)
                 }
             }
@@ -767,7 +791,11 @@ void pack_x3_weights(const float *conv1_w, const float *conv2_w, float *wx1, flo
             // stream position -> canonical slab (split_conv1_index): waves 4-7 walk every (tap, image) step as
             // [12 cell slabs of levels 2 + 3][4 pixel slabs of level 1], waves 0-3 the other way round
             int slab = pos;
+#ifdef XF_PPAR
+            if (false) {
+#else
             if (w >= 4 && pos >= 4) {
+#endif
                 const int step = (pos - 4) / 16, j = (pos - 4) % 16;
                 slab = 4 + step * 16 + ((j < 12) ? 4 + j : j - 12);
             }
