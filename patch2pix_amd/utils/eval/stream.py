@@ -26,6 +26,28 @@ def _load(job):
     return idx, t1, t2, np.array([tuple(s1) + tuple(s2)])
 
 
+_pin_pool = {}      # (shape) -> [[pinned tensor, event-or-None], ...] ring of staging buffers for the image batches
+
+
+def _upload(tensors, device):
+    """Stack a list of equally shaped CPU image tensors into a recycled PINNED batch buffer and start one asynchronous
+    copy to the device.  (Stacking into pageable memory and copying from there cost 100-190 ms per batch of 8 pairs --
+    more than the whole GPU work of the batch.)"""
+    shape = (len(tensors),) + tuple(tensors[0].shape)
+    ring = _pin_pool.setdefault(shape, {"slots": [], "turn": 0})
+    if len(ring["slots"]) < 4:
+        ring["slots"].append([torch.empty(shape, dtype=tensors[0].dtype).pin_memory(), None])
+    slot = ring["slots"][ring["turn"] % len(ring["slots"])]
+    ring["turn"] += 1
+    if slot[1] is not None:
+        slot[1].synchronize()              # the copy that last read this buffer has finished
+    torch.stack(tensors, out=slot[0])
+    dev = slot[0].to(device, non_blocking=True)
+    slot[1] = torch.cuda.Event()
+    slot[1].record(torch.cuda.current_stream(device))
+    return dev
+
+
 def _finish(net, ticket, metas, ncn_thres, mutual, io_thres):
     fine, conf, coarse = net.fine_from_ticket(ticket, ncn_thres=ncn_thres, mutual=mutual)
     # one device-to-host copy for the whole batch: [fine x1,y1,x2,y2 | confidence | coarse x1,y1,x2,y2]
@@ -57,8 +79,8 @@ def estimate_matches_stream(net, pairs, ksize=2, ncn_thres=0.0, mutual=True, io_
             """Backbone on the 2*B images of the current group, coarse stage enqueued, ticket queued."""
             if not group:
                 return
-            im1 = torch.stack([g[1] for g in group]).to(net.device, non_blocking=True)
-            im2 = torch.stack([g[2] for g in group]).to(net.device, non_blocking=True)
+            im1 = _upload([g[1] for g in group], net.device)
+            im2 = _upload([g[2] for g in group], net.device)
             if im1.shape == im2.shape:
                 feats = net.extract.pyramid(torch.cat([im1, im2]))
                 n = im1.shape[0]
