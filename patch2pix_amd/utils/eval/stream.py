@@ -33,6 +33,8 @@ def _upload(tensors, device):
     """Stack a list of equally shaped CPU image tensors into a recycled PINNED batch buffer and start one asynchronous
     copy to the device.  (Stacking into pageable memory and copying from there cost 100-190 ms per batch of 8 pairs --
     more than the whole GPU work of the batch.)"""
+    if torch.device(device).type != "cuda":            # host-logic tests drive the generator with a CPU stand-in of the net
+        return torch.stack(tensors).to(device)
     shape = (len(tensors),) + tuple(tensors[0].shape)
     ring = _pin_pool.setdefault(shape, {"slots": [], "turn": 0})
     if len(ring["slots"]) < 4:
