@@ -19,6 +19,36 @@ def _normalised(img):
     return (torch.from_numpy(arr) - torch.from_numpy(_MEAN)) / torch.from_numpy(_STD)
 
 
+_LUT = {}
+
+
+def normalise_pixels(pixels):
+    """uint8 [B,H,W,3] (any device) -> float32 [B,3,H,W], bit-identical to `_normalised`: the normalised value depends
+    only on (channel, byte), so it is looked up in a [3,256] table computed ON THE HOST with the reference's three
+    operations (/255, -mean, /std).  (The same arithmetic on the GPU is not bit-identical: its division by a constant is
+    a multiplication by the reciprocal.)  Lets the entry points upload uint8 pixels -- a quarter of the bytes -- and
+    skip the float conversion on the host."""
+    dev = pixels.device
+    if dev not in _LUT:
+        v = np.arange(256, dtype=np.float32)[None, :].repeat(3, 0).reshape(3, 256, 1)
+        v /= 255.0
+        _LUT[dev] = ((torch.from_numpy(v) - torch.from_numpy(_MEAN)) / torch.from_numpy(_STD)).reshape(3, 256).to(dev)
+    lut = _LUT[dev]
+    idx = pixels.permute(0, 3, 1, 2).long()                                  # [B,3,H,W]
+    return torch.gather(lut[None, :, :, None].expand(idx.shape[0], 3, 256, idx.shape[3]), 2, idx)
+
+
+def load_im_pixels(im_path, k_size=2, upsample=16, imsize=None):
+    """`load_im_flexible` up to (not including) the normalisation: -> (uint8 tensor [H,W,3], (wo/wt, ho/ht))."""
+    img = Image.open(im_path).convert("RGB")
+    wo, ho = img.width, img.height
+    if not (imsize and imsize > 0) or imsize > max(wo, ho):
+        imsize = max(wo, ho)
+    wt, ht = cal_rescale_size(imsize, wo, ho, k_size=k_size, scale_factor=1.0 / upsample)
+    img = img.resize((wt, ht), Image.BICUBIC)
+    return torch.from_numpy(np.array(img, dtype=np.uint8)), (wo / wt, ho / ht)
+
+
 def load_im_tensor(im_path, device, imsize=None, with_gray=True):
     """-> (im [1,3,H,W] normalised, gray [1,1,H,W] in [0,1], (wo/wt, ho/ht)) or (im, scale) without grey."""
     im = Image.open(im_path)

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from ..common.setup_helper import load_weights
-from ..datasets.preprocess import load_im_flexible, load_im_tensor
+from ..datasets.preprocess import load_im_flexible, load_im_pixels, load_im_tensor, normalise_pixels
 from ...networks.patch2pix import Patch2Pix
 from ... import ops
 
@@ -91,8 +91,10 @@ def _load_pair(net, im1, im2, ksize, imsize):
     """Both images as [1,3,H,W] tensors on the device + the (1,4) factors back to original pixels."""
     tensors, factors = [], ()
     for im in (im1, im2):
-        t, scale_wh = load_im_flexible(im, ksize, net.upsample, imsize=imsize)
-        tensors.append(t.unsqueeze(0).to(net.device))
+        # PIL decode + bicubic resize on the host like the reference (load_im_flexible); the uint8 pixels go to the device
+        # and are normalised there (bit-identical, a quarter of the upload)
+        pixels, scale_wh = load_im_pixels(im, ksize, net.upsample, imsize=imsize)
+        tensors.append(normalise_pixels(pixels.unsqueeze(0).to(net.device)))
         factors += tuple(scale_wh)
     return tensors[0], tensors[1], np.array([factors])
 

@@ -16,13 +16,13 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 import torch
 
-from ..datasets.preprocess import load_im_flexible
+from ..datasets.preprocess import load_im_pixels, normalise_pixels
 
 
 def _load(job):
     idx, im1, im2, ksize, upsample, imsize = job
-    t1, s1 = load_im_flexible(im1, ksize, upsample, imsize=imsize)
-    t2, s2 = load_im_flexible(im2, ksize, upsample, imsize=imsize)
+    t1, s1 = load_im_pixels(im1, ksize, upsample, imsize=imsize)          # uint8 [H,W,3]: normalised on the device
+    t2, s2 = load_im_pixels(im2, ksize, upsample, imsize=imsize)
     return idx, t1, t2, np.array([tuple(s1) + tuple(s2)])
 
 
@@ -30,11 +30,11 @@ _pin_pool = {}      # (shape) -> [[pinned tensor, event-or-None], ...] ring of s
 
 
 def _upload(tensors, device):
-    """Stack a list of equally shaped CPU image tensors into a recycled PINNED batch buffer and start one asynchronous
-    copy to the device.  (Stacking into pageable memory and copying from there cost 100-190 ms per batch of 8 pairs --
+    """Stack a list of equally shaped uint8 [H,W,3] images into a recycled PINNED batch buffer, start one asynchronous
+    copy to the device and normalise there -> float32 [B,3,H,W].  (Stacking into pageable memory and copying from there cost 100-190 ms per batch of 8 pairs --
     more than the whole GPU work of the batch.)"""
     if torch.device(device).type != "cuda":            # host-logic tests drive the generator with a CPU stand-in of the net
-        return torch.stack(tensors).to(device)
+        return normalise_pixels(torch.stack(tensors).to(device))
     shape = (len(tensors),) + tuple(tensors[0].shape)
     ring = _pin_pool.setdefault(shape, {"slots": [], "turn": 0})
     if len(ring["slots"]) < 4:
@@ -47,7 +47,7 @@ def _upload(tensors, device):
     dev = slot[0].to(device, non_blocking=True)
     slot[1] = torch.cuda.Event()
     slot[1].record(torch.cuda.current_stream(device))
-    return dev
+    return normalise_pixels(dev)
 
 
 def _finish(net, ticket, metas, ncn_thres, mutual, io_thres):

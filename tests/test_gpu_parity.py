@@ -931,3 +931,16 @@ def test_stream_against_reference_golden(dev, tmp_path):
         assert m.dtype == np.float64 and s.dtype == np.float32 and c.dtype == np.float64
         assert np.array_equal(c, g["fine_coarse"])
         assert np.abs(m - g["fine_matches"]).max() <= COORD_TOL and np.abs(s - g["fine_scores"]).max() <= SCORE_TOL
+
+
+def test_device_normalisation_is_bit_identical(dev):
+    """utils/datasets/preprocess.py::normalise_pixels on the GPU == the host normalisation of load_im_flexible (the
+    reference's /255, -mean, /std, preprocess.py:32-60) for every uint8 value in every channel."""
+    from PIL import Image
+    from patch2pix_amd.utils.datasets.preprocess import _normalised, normalise_pixels
+    px = np.zeros((16, 16, 3), np.uint8)
+    flat = px.reshape(-1, 3)
+    flat[:, 0], flat[:, 1], flat[:, 2] = np.arange(256), np.arange(256)[::-1], (np.arange(256) * 7) % 256
+    host = _normalised(Image.fromarray(px))
+    got = normalise_pixels(torch.from_numpy(px)[None].to(dev))[0].cpu()
+    assert torch.equal(host, got)
