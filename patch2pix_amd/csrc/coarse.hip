@@ -937,11 +937,14 @@ extern "C" int p2p_coarse_forward_batch(const float *featA, const float *featB, 
 
         const dim3 cgrid(ceil_div(nB, CT), ceil_div(nA, CT), nz);
         if (corr_x3()) {
-            static bool attr_set = false;
+            int dev = 0;
+            P2P_HIP_CHECK(hipGetDevice(&dev));
+            static bool attr_set_dev[64] = {false};      // per device: a process may drive several GPUs
+            const bool attr_set = dev < 64 && attr_set_dev[dev];
             if (!attr_set) {
                 P2P_HIP_CHECK(hipFuncSetAttribute((const void *)corr_pool_x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CX_MAT));
                 P2P_HIP_CHECK(hipFuncSetAttribute((const void *)corr_pool_x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CX_MAT));
-                attr_set = true;
+                if (dev < 64) attr_set_dev[dev] = true;
             }
             hipLaunchKernelGGL(prep_kernel<true>, dim3(ceil_div(nA, PREP_P), 1, nz), dim3(256), 0, stream, fA, fnA, C, hA, wA, ksize,
                                (size_t)C * nA, sWs);

@@ -216,11 +216,13 @@ extern "C" int p2p_filter_coarse_batch(const int64_t *matches, const float *scor
     int npad = 2;
     while (npad < n) npad <<= 1;
     const size_t lds = (size_t)npad * 16;
-    static bool attr_set = false;
-    if (!attr_set) {
+    int dev = 0;
+    P2P_HIP_CHECK(hipGetDevice(&dev));
+    static bool attr_set[64] = {false};      // per device: a process may drive several GPUs
+    if (dev < 64 && !attr_set[dev]) {
         P2P_HIP_CHECK(hipFuncSetAttribute((const void *)filter_coarse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           FILTER_MAX_ROWS * 16));
-        attr_set = true;
+        attr_set[dev] = true;
     }
     FilterArgs a{(const long long *)matches, scores, n, npad, ncn_thres, mutual, (long long *)out_matches, out_scores, out_counts};
     hipLaunchKernelGGL(filter_coarse_kernel, dim3(batch), dim3(FT), lds, (hipStream_t)stream, a);

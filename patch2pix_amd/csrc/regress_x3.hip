@@ -283,7 +283,6 @@ __device__ __forceinline__ void split3(const f32x4 &xa, const f32x4 &xb, float s
 __global__ __launch_bounds__(NT, 2) void regress_x3_kernel(RegressArgs args) {
     P2P_DYN_SHARED(unsigned char, smb);
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int prop = blockIdx.x;
     int it = 0;
