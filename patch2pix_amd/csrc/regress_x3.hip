@@ -20,7 +20,10 @@
 //     PER CELL ROW (one m-tile of 32 rows instead of two m-tiles of pixels: half the MFMAs) from tiles that
 //     were split into the three bf16 planes ONCE, when they were gathered; the per-pixel L2 scale and the
 //     cell -> pixel expansion are applied when the partial sum T[cell row][n] is folded into the accumulators
-//     (acc[pixel][n] += scale[pixel] * T[row(pixel)][n], through a per-wave LDS buffer): -18.6 % MFMAs.
+//     (acc[pixel][n] += scale[pixel] * T[row(pixel)][n], through LDS fold buffers): -18.6 % MFMAs.  Level 3 (128 of
+//     those channels) has only 3 x 3 cells per image: it runs on 16-row tiles (v_mfma_f32_16x16x32_bf16, rows = the 9
+//     cells) into its own fold buffer T3, level 2 on a 32-row tile into T2: -24.8 % MFMAs in total.  (T2 is shared by
+//     the two waves of a SIMD pair -- their folds never overlap under the turn protocol -- which is what pays for T3.)
 //   * conv1, levels 0 and 1 (no de-duplication possible at stride 2): fp32 in LDS, scaled and split in registers
 //     (40 VALU operations per 8 values), software-pipelined against the MFMAs of the other m-tile.
 //   * conv2: its input H = BN1(conv1) is split into the three planes ONCE per proposal (not once per tap and
@@ -46,8 +49,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // conv1 phase, per image: level 1 as fp32 [81 cells][64 ch (+16 B pad)]; levels 2 and 3 as three bf16 planes
 // [plane][25 cells + a zero cell][64 ch (+16 B)] and [plane][9 cells + a zero cell][128 ch (+16 B)].  Then level 0 raw [img][3][256] and one
 // shared region that is, in turn: the fp32 copy of levels 2/3 the scale pass reads; the pre-scaled level-0 im2col
-// block A0[64 px][64 K fp32 (+16 B)] (K = img*32 + tap*3 + c, 27 real per image); the per-wave fold buffers
-// T[8 waves][28 cell rows][64 n] fp32.  Then the fold table [img][17][17] of {scale, T row offset} (row/column 0 =
+// block A0[64 px][64 K fp32 (+16 B)] (K = img*32 + tap*3 + c, 27 real per image); the fold buffers
+// T2[4 wave pairs][28 level-2 rows][64 n] and T3[8 waves][9 level-3 rows][64 n] fp32.  Then the fold table [img][17][17] of {scale, T row offset} (row/column 0 =
 // the zero padding ring of the convolution) and the per-pixel scale [2][256].
 constexpr int XST1 = 64 * 4 + 16;                                 // bytes per level-1 cell
 constexpr int XNC1 = 81;
@@ -201,6 +204,32 @@ __device__ __forceinline__ void split3(const f32x4 &xa, const f32x4 &xb, float s
 #define XCSLAB(HALF, SC, SN, NP, NPL, BC0, BC1, BN0, BN1, AH)                             \
     { XLOADP(SN, NP, NPL) XLOADB(BN0, AH) XLOADB(BN1, (AH) + 1)                                                       \
       HALF(t0, t1, SC, BC0, BC1) XLPIPE(3, 12) __builtin_amdgcn_sched_barrier(0); }
+#ifndef XF_L3_32
+#define XF_L3_16 1
+#endif
+#ifdef XF_L3_16
+#if defined(XF_NO_PINGPONG) || defined(XF_CONV1_PAIR) || defined(XF_PPAR)
+#error "the 16-row level-3 path shares the T2 fold buffers between the halves of a SIMD pair: it needs the exclusive-turn protocol (add -DXF_L3_32 to these experiments)"
+#endif
+// Level 3 (9 cells per image) on 16-row tiles, v_mfma_f32_16x16x32_bf16 (A: lane l = row l & 15, K block
+// l >> 4; B: column l & 15; D: rows 4 * (l >> 4) + r, column l & 15).  One "pseudo-slab" = one K step of 32 channels
+// against two 16-column n-tiles = 12 MFMAs of 16 cycles and two weight units.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+#define X16MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+#define X16HALF_(C0IN, C1IN, CU0, CU1, SP, BU0, BU1)                                     \
+    CU0 = X16MFMA(SP[2], BU0[0], C0IN); CU1 = X16MFMA(SP[2], BU1[0], C1IN);              \
+    CU0 = X16MFMA(SP[1], BU0[1], CU0); CU1 = X16MFMA(SP[1], BU1[1], CU1);                \
+    CU0 = X16MFMA(SP[0], BU0[2], CU0); CU1 = X16MFMA(SP[0], BU1[2], CU1);                \
+    CU0 = X16MFMA(SP[1], BU0[0], CU0); CU1 = X16MFMA(SP[1], BU1[0], CU1);                \
+    CU0 = X16MFMA(SP[0], BU0[1], CU0); CU1 = X16MFMA(SP[0], BU1[1], CU1);                \
+    CU0 = X16MFMA(SP[0], BU0[0], CU0); CU1 = X16MFMA(SP[0], BU1[0], CU1);
+#define X16HALF(CU0, CU1, SP, BU0, BU1) X16HALF_(CU0, CU1, CU0, CU1, SP, BU0, BU1)
+#define X16HALFZ(CU0, CU1, SP, BU0, BU1) X16HALF_(zero4, zero4, CU0, CU1, SP, BU0, BU1)
+// LOADNEXT: the LDS reads this pseudo-slab carries for a later one (or nothing)
+#define X16SLAB(HALF, UA, UB, SC, LOADNEXT, BC0, BC1, BN0, BN1, AH)                       \
+    { LOADNEXT XLOADB(BN0, AH) XLOADB(BN1, (AH) + 1)                                                                  \
+      HALF(UA, UB, SC, BC0, BC1) __builtin_amdgcn_sched_barrier(0); }
+#endif
 // conv2: both m-tiles from the planes (AC0, AC1); (AN0, AN1) <- the next slab's (addresses NP0, NP1)
 // Two waves of a SIMD that both issue MFMAs back to back get ~57 % of the matrix pipe between them, one wave alone
 // 85 % (measured); so the two halves of the work-group take turns, two slabs (48 MFMAs) at a time: XPP() = the two
@@ -445,7 +474,13 @@ __global__ __launch_bounds__(NT, 2) void regress_x3_kernel(RegressArgs args) {
             const float sc = 1.0f / sqrtf(ss + 1e-6f);
             scale[tidv] = sc;
             // fold table: entry (py + 1, px + 1) = {scale of the pixel, byte offset of its cell row in T}
+#ifdef XF_L3_16
+            const int c3 = patch_cell(XY0(img), py, 3, I.H[img]) * 3 + patch_cell(XX0(img), px, 3, I.W[img]);
+            *(f32x2 *)(smb + XTAB + img * XTABIMG + ((py + 1) * 17 + px + 1) * 8) =
+                (f32x2){sc, __int_as_float(c2 * XTROW | (c3 * XTROW) << 16)};
+#else
             *(f32x2 *)(smb + XTAB + img * XTABIMG + ((py + 1) * 17 + px + 1) * 8) = (f32x2){sc, __int_as_float(c2 * XTROW)};
+#endif
             if (tidv < 2 * 33) {     // ring = the zero padding of conv1: scale 0
                 const int im = tidv / 33, q = tidv - im * 33;
                 const int idx = (q < 17) ? q : (q - 16) * 17;
@@ -496,7 +531,15 @@ __global__ __launch_bounds__(NT, 2) void regress_x3_kernel(RegressArgs args) {
             XT(3)
             // this lane's row of the cell tile: level-2 cell l31 (rows >= 25 are never read back) and its level-3 parent
             const int c2y = (l31 < 25) ? l31 / 5 : 0, c2x = (l31 < 25) ? l31 - 5 * (l31 / 5) : 0;
+#ifdef XF_L3_16
+            // T2 (level-2 rows) is shared by wave w and w + 4: their folds never overlap under the turn protocol (G1's is
+            // over before e3, G0's runs between e3 and e4); T3 (9 level-3 rows) is private and written inside the C turn
+            float *Tw = (float *)(smb + XSHARED + (wave & 3) * XTW) + l31;
+            float *T3w = (float *)(smb + XSHARED + 4 * XTW + wave * (9 * XTROW));
+            const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
+#else
             float *Tw = (float *)(smb + XSHARED + wave * XTW) + l31;
+#endif
             // The K-ranges (tap, image) are walked in 18 steps.  A step = the pixel slabs of level 1 (P), the cell slabs
             // of levels 2 + 3 (C) and the fold (F).  Waves 0-3 run P(i) C(i) F(i); waves 4-7 -- each shares its SIMD with
             // one of waves 0-3 -- run C(i) F(i) P(i) (their weight stream is packed in that order), so that a fold, which
@@ -557,7 +600,43 @@ __global__ __launch_bounds__(NT, 2) void regress_x3_kernel(RegressArgs args) {
                     const unsigned char *q2 = smb + a2, *q3 = smb + a3;
                     f32x16 t0, t1;
                     XPB_C0(grp)
-#ifdef XF_SKIP_C
+#if defined(XF_L3_16)
+                    {
+                        (void)q3;
+                        // level 3 first: 4 K steps of 32 channels x 4 n-tiles of 16 columns, rows = the 9 cells
+                        const int l16 = (tidv & 15), kb = (tidv >> 4) & 3;
+                        const unsigned char *q3r = smb + img * XIMG + YOFF3 + ((l16 < 9) ? l16 : YNC3) * YST3 + kb * 16;
+                        f32x4v u0, u1, u2, u3;
+                        XLOADP(S0, q3r, YPL3)
+                        X16SLAB(X16HALFZ, u0, u1, S0, XLOADP(S1, q3r + 64, YPL3), B0, B1, B2, B3, 2)
+                        X16SLAB(X16HALFZ, u2, u3, S0, , B2, B3, B0, B1, 4)
+                        XWADV(4)
+                        X16SLAB(X16HALF, u0, u1, S1, XLOADP(S0, q3r + 128, YPL3), B0, B1, B2, B3, 2)
+                        X16SLAB(X16HALF, u2, u3, S1, , B2, B3, B0, B1, 4)
+                        XWADV(4)
+                        X16SLAB(X16HALF, u0, u1, S0, XLOADP(S1, q3r + 192, YPL3), B0, B1, B2, B3, 2)
+                        X16SLAB(X16HALF, u2, u3, S0, , B2, B3, B0, B1, 4)
+                        XWADV(4)
+                        X16SLAB(X16HALF, u0, u1, S1, XLOADP(S0, q2, YPL2), B0, B1, B2, B3, 2)
+                        X16SLAB(X16HALF, u2, u3, S1, , B2, B3, B0, B1, 4)
+                        XWADV(4)
+                        // T3[row = 4 * kb + r][column 16 * nt + l16]
+                        P2P_WAVE_SYNC();
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (4 * kb + r < 9) {
+                                float *d = T3w + (4 * kb + r) * 64 + l16;
+                                d[0] = u0[r]; d[16] = u1[r]; d[32] = u2[r]; d[48] = u3[r];
+                            }
+                        // level 2: 4 slabs of 16 channels, rows = level-2 cells
+                        XCSLAB(XHALFZ, S0, S1, q2 + 32, YPL2, B0, B1, B2, B3, 2)
+                        XCSLAB(XHALF, S1, S0, q2 + 64, YPL2, B2, B3, B0, B1, 4)
+                        XWADV(4)
+                        XCSLAB(XHALF, S0, S1, q2 + 96, YPL2, B0, B1, B2, B3, 2)
+                        XCSLAB(XHALF, S1, S0, q2 + 96, YPL2, B2, B3, B0, B1, 4)
+                        XWADV(4)
+                    }
+#elif defined(XF_SKIP_C)
                     t0 = acc00; t1 = acc01; XWADV(24) (void)q2; (void)q3;
 #else
                     // 12 slabs of 16 channels = 32 bytes of bf16 per plane
@@ -598,9 +677,18 @@ __global__ __launch_bounds__(NT, 2) void regress_x3_kernel(RegressArgs args) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
                                 const f32x2 e = *(const f32x2 *)(tabp + ((8 * t + 2 * (r >> 2)) * 17 + 2 * (r & 3)) * 8);
+#ifdef XF_L3_16
+                                const int offs = __float_as_int(e[1]);
+                                const float *g = (const float *)(Tr + (offs & 0xffff));
+                                const float *h3 = (const float *)((const unsigned char *)(T3w + l31) + (offs >> 16));
+                                const float v0 = g[0] + h3[0], v1 = g[32] + h3[32];
+                                if (t == 0) { acc00[r] = fmaf(e[0], v0, acc00[r]); acc01[r] = fmaf(e[0], v1, acc01[r]); }
+                                else        { acc10[r] = fmaf(e[0], v0, acc10[r]); acc11[r] = fmaf(e[0], v1, acc11[r]); }
+#else
                                 const float *g = (const float *)(Tr + __float_as_int(e[1]));
                                 if (t == 0) { acc00[r] = fmaf(e[0], g[0], acc00[r]); acc01[r] = fmaf(e[0], g[32], acc01[r]); }
                                 else        { acc10[r] = fmaf(e[0], g[0], acc10[r]); acc11[r] = fmaf(e[0], g[32], acc11[r]); }
+#endif
                                 if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // four rows in flight, not all 32
                             }
                     }
@@ -809,6 +897,30 @@ void pack_x3_weights(const float *conv1_w, const float *conv2_w, float *wx1, flo
                 const int step = (pos - 4) / 16, j = (pos - 4) % 16;
                 slab = 4 + step * 16 + ((j < 12) ? 4 + j : j - 12);
             }
+#ifdef XF_L3_16
+            // inside a step the cell range is walked as [level 3: 8 pseudo-slabs in 16x16x32 order][level 2: 4 slabs]
+            if (slab >= 4) {
+                const int step = (slab - 4) / 16, sc = (slab - 4) % 16;       // canonical: 0-3 level 1, 4-7 level 2, 8-15 level 3
+                const int rel = (w >= 4) ? (pos - 4) % 16 : (pos - 4) % 16 - 4;   // position inside the cell range (waves 0-3: after P)
+                if (sc >= 4) {
+                    if (rel < 8) {          // pseudo-slab rel: K step rel / 2, n-tiles 2 * (rel & 1) + u
+                        const int ks = rel / 2, img = step & 1, tap = step >> 1;
+                        for (int u = 0; u < 2; ++u) {
+                            const size_t base = ((size_t)w * (S1_UNITS + XPF) + pos * 2 + u) * 192;
+                            const int nt = 2 * (rel & 1) + u;
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int j = 0; j < 8; ++j) {
+                                    const int n = 64 * w + 16 * nt + (lane & 15);
+                                    const int ch = img * 259 + 131 + 32 * ks + 8 * (lane >> 4) + j;
+                                    put3(d1, base, lane, j, conv1_w[((size_t)n * 518 + ch) * 9 + tap]);
+                                }
+                        }
+                        continue;
+                    }
+                    slab = 4 + step * 16 + 4 + (rel - 8);       // level-2 slab rel - 8
+                }
+            }
+#endif
             for (int u = 0; u < 2; ++u) {
                 const int unit = pos * 2 + u;
                 const size_t base = ((size_t)w * (S1_UNITS + XPF) + unit) * 192;

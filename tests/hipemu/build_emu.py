@@ -21,6 +21,7 @@ def build(force=False, verbose=False):
     cxx = os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
     cmd = [cxx, "-std=c++17", "-O2", "-g0", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-I" + HERE,
            "-Wno-unused-value", "-Wno-unknown-attributes", "-o", OUT]
+    cmd += os.environ.get("HIPEMU_DEFINES", "").split()          # e.g. -DXF_L3_16 to run an experiment build on the CPU
     for s in SOURCES:
         cmd += ["-x", "c++", os.path.join(CSRC, s)]
     cmd += ["-x", "c++", os.path.join(HERE, "hipemu.cpp")]

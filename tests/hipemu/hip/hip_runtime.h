@@ -159,3 +159,28 @@ static inline hipemu_f32x16 hipemu_mfma_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf
     return c;
 }
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu_mfma_32x32x16_bf16((a), (b), (c))
+
+// v_mfma_f32_16x16x32_bf16: A 16x32, B 32x16 in bf16, fp32 accumulate.  Lane l holds A[l&15][8*(l>>4) + i],
+// B[8*(l>>4) + i][l&15], i = 0..7; register r of C/D is row 4*(l>>4) + r, column l&15.
+typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
+static inline hipemu_f32x4 hipemu_mfma_16x16x32_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x4 c) {
+    struct { unsigned short a[8], b[8]; } mine;
+    memcpy(mine.a, &a, 16);
+    memcpy(mine.b, &b, 16);
+    const unsigned char *all = hipemu::wave_gather(&mine, sizeof(mine));
+    const int lane = hipemu::ctx().thread.x & 63, col = lane & 15, blk = lane >> 4;
+    auto bf = [](unsigned short u) { return __uint_as_float((unsigned)u << 16); };
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * blk + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) {
+            unsigned short ua, ub;
+            memcpy(&ua, all + (row + 16 * (k >> 3)) * 32 + 2 * (k & 7), 2);
+            memcpy(&ub, all + (col + 16 * (k >> 3)) * 32 + 16 + 2 * (k & 7), 2);
+            acc += bf(ua) * bf(ub);
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) hipemu_mfma_16x16x32_bf16((a), (b), (c))
