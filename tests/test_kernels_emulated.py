@@ -101,12 +101,13 @@ def test_regressors_against_reference_golden(mode, emu, sd):
         assert (out["probs1"] - torch.from_numpy(g[tag + "_probs"][:n])).abs().max() <= SCORE_TOL
 
 
-def test_regressor_chain_and_image_borders(emu, sd):
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x2"])
+def test_regressor_chain_and_image_borders(mode, emu, sd):
     """Mid -> fine inside one launch (the fine patch is centred on the truncated mid match, its base is the
     un-truncated one), with proposals on the image corners where every level of the patch clamps."""
     sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
-    mid = emu_lib.regressor_create(emu, sub("regress_mid."), "bf16x2")
-    fine = emu_lib.regressor_create(emu, sub("regress_fine."), "bf16x2")
+    mid = emu_lib.regressor_create(emu, sub("regress_mid."), mode)
+    fine = emu_lib.regressor_create(emu, sub("regress_fine."), mode)
     H, W = 48, 64
     p1, p2 = synthetic.make_pyramid(7, H, W), synthetic.make_pyramid(8, H, W)
     props = torch.tensor([[0, 0, W, H], [W, H, 0, 0], [31, 17, 5, 40]])
@@ -123,12 +124,13 @@ def test_regressor_chain_and_image_borders(emu, sd):
     assert (out["probs2"] - ref_finep).abs().max() <= SCORE_TOL
 
 
-def test_regress_batch_items_of_different_sizes(emu, sd):
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x2"])
+def test_regress_batch_items_of_different_sizes(mode, emu, sd):
     """p2p_regress_batch over items (pairs) of different image sizes, one of them empty == one call per item."""
     import ctypes
     from patch2pix_amd import _lib as real
     sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
-    mid = emu_lib.regressor_create(emu, sub("regress_mid."), "bf16x2")
+    mid = emu_lib.regressor_create(emu, sub("regress_mid."), mode)
     sizes, counts = [(16, 24), (24, 16), (8, 8), (16, 16)], [2, 1, 0, 1]
     g = torch.Generator().manual_seed(4)
     pyr1 = [synthetic.make_pyramid(200 + i, h, w)[:4] for i, (h, w) in enumerate(sizes)]
@@ -259,14 +261,15 @@ def test_device_filter_coarse_against_oracle(seed, emu):
         assert emu_lib.filter_coarse_batch(emu, torch.tensor([[bad, [1, 2, 3, 4]]]), torch.rand(1, 2), 0.0, True) == [None]
 
 
-def test_regress_with_device_counts(emu, sd):
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x2"])
+def test_regress_with_device_counts(mode, emu, sd):
     """p2p_regress_batch_dev: every item owns `stride` slots, the first counts[i] hold proposals; used slots equal the
     per-item call bit for bit, the others are not touched."""
     import ctypes
     from patch2pix_amd import _lib as real
     sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
-    mid = emu_lib.regressor_create(emu, sub("regress_mid."), "bf16x2")
-    fine = emu_lib.regressor_create(emu, sub("regress_fine."), "bf16x2")
+    mid = emu_lib.regressor_create(emu, sub("regress_mid."), mode)
+    fine = emu_lib.regressor_create(emu, sub("regress_fine."), mode)
     sizes, counts, stride = [(16, 24), (24, 16), (8, 8)], [2, 0, 1], 3
     g = torch.Generator().manual_seed(4)
     pyr1 = [synthetic.make_pyramid(200 + i, h, w)[:4] for i, (h, w) in enumerate(sizes)]
