@@ -325,3 +325,31 @@ def test_match_tail_against_reference_semantics(emu):
         assert np.array_equal(got[b][0].numpy(), up * f) and np.array_equal(got[b][1].numpy(), s)
         assert np.array_equal(got[b][2].numpy(), up * co) and got[b][0].dtype == torch.float64
     assert len(got[2][1]) == 300
+
+
+def test_correlation_modes_agree(tmp_path):
+    """The two arithmetic modes of the correlation GEMM (bf16x3 planes, the default, and the exact fp32 MFMA behind
+    P2P_CORR_MODE=f32) in separate processes (the mode is read once): same relocalisation argmaxes, same matches, pooled
+    volume equal to fp32 rounding."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, "tests"); sys.path.insert(0, "."); sys.path.insert(0, "tests/hipemu")
+import emu_lib, golden_util as gu
+from patch2pix_amd.utils import synthetic
+emu = emu_lib.load(); ncn = emu_lib.ncn_create(emu, gu.state_dict(0))
+p1, p2 = synthetic.make_correlated_pyramids(78, 80, 96)
+corr, delta = emu_lib.coarse_forward_batch(emu, ncn, p1[4][None], p2[4][None], 2)
+m, s = emu_lib.coarse_matches_batch(emu, corr, delta, 2, 8)
+torch.save((corr, delta, m, s), sys.argv[1])
+'''
+    outs = {}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("bf16x3", "f32"):
+        f = str(tmp_path / f"{mode}.pt")
+        subprocess.check_call([sys.executable, "-c", code, f], env=dict(os.environ, P2P_CORR_MODE=mode), cwd=root)
+        outs[mode] = torch.load(f)
+    a, b = outs["bf16x3"], outs["f32"]
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert torch.allclose(a[0], b[0], rtol=2e-4, atol=1e-9) and torch.allclose(a[3], b[3], rtol=1e-4)
