@@ -294,6 +294,11 @@ def main():
                     and rec.get("config", "A") == args.config and rec.get("source_hash") == source_hash()):
                 roof["traffic"] = rec.get("hbm_bytes_per_launch")
                 roof["traffic_source"] = rec.get("source")
+                roof["traffic_note"] = ("FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE of the kernel per launch = requests on the "
+                                        "L2's fabric side: Infinity-Cache hits are included, so this is an upper bound of the HBM "
+                                        "bytes; the compulsory bytes of the launch are ~1 GB (16 x 61 MB of pyramids + 57 MB of "
+                                        "weights), the rest are L2 capacity misses of the 28.5 MB-per-level weight stream, which "
+                                        "lives in the 256 MB Infinity Cache")
         # the path's compulsory HBM bytes per pair against the 8 TB/s roofline, as north_star asks
         alg_bytes = 118e6 if args.config == "A" else 0.42e9
         out = {
