@@ -143,10 +143,17 @@ def case_full_size(ref, net, name, seed, H, W, ptmax):
     print(name, "rows", m.shape[1], "mutual", fm[0].shape[0], "proposals", cm[0].shape[0])
 
 
-def case_real_pair(ref, name, pair_dir, imsize):
+def case_real_pair(ref, name, pair_dir, imsize, contrast=None):
     """The reference's estimate_matches (utils/eval/model_helper.py:64-109) on a real image pair of its examples/
-    directory (copied to tests/golden/images), synthetic checkpoint in the reference's own schema."""
-    ckpt = synthetic.make_checkpoint(SD_SEED)
+    directory (copied to tests/golden/images), synthetic checkpoint in the reference's own schema.  `contrast`: the
+    checkpoint variant whose backbone yields sparse, discriminative features (synthetic.contrast_shift); the shift the
+    fixture was made with is stored in it."""
+    extra = {}
+    if contrast is not None:
+        extra["contrast_shift"] = np_(synthetic.contrast_shift(synthetic.make_state_dict(SD_SEED), contrast))
+        ckpt = synthetic.make_checkpoint(SD_SEED, contrast=torch.from_numpy(extra["contrast_shift"]))
+    else:
+        ckpt = synthetic.make_checkpoint(SD_SEED)
     im1, im2 = os.path.join(GOLDEN, "images", pair_dir, "1.jpg"), os.path.join(GOLDEN, "images", pair_dir, "2.jpg")
     with tempfile.TemporaryDirectory() as td:
         torch.save(ckpt, os.path.join(td, "ckpt.pth"))
@@ -158,10 +165,16 @@ def case_real_pair(ref, name, pair_dir, imsize):
         # the layer-3 features the reference's backbone produced on this CPU: lets a test tell backbone drift
         # (another CPU / MIOpen) from a difference in the matching path
         t1, _ = ref.model_helper.load_im_flexible(im1, 2, net.upsample, imsize=imsize)
+        t2, _ = ref.model_helper.load_im_flexible(im2, 2, net.upsample, imsize=imsize)
         with torch.no_grad():
             feat = net.extract(t1[None], early_feat=True)
+            # every coarse row before filter_coarse (patch2pix.py:240-248 without the filter): pins each argmax
+            corr4d, delta4d = net.forward(t1[None], t2[None], ksize=2)
+            rows, row_scores = net.cal_coarse_matches(corr4d, delta4d, ksize=2, upsample=net.upsample, center=True)
+        extra["all_rows"] = np_(rows[0]).astype(np.int16)
+        extra["all_scores"] = np_(row_scores[0])
     np.savez_compressed(os.path.join(GOLDEN, name), pair=pair_dir, imsize=(-1 if imsize is None else imsize), sd_seed=SD_SEED,
-                        feat1_checksum=checksum([feat]), feat1_shape=np.array(feat.shape), **res)
+                        feat1_checksum=checksum([feat]), feat1_shape=np.array(feat.shape), **extra, **res)
     print(name, "fine", res["fine_matches"].shape, "coarse", res["coarse_matches"].shape, "feat", tuple(feat.shape))
 
 
@@ -190,6 +203,7 @@ def main():
     case_estimate_matches(ref, "estimate_matches_240x320", 51, 240, 320, None)
     case_estimate_matches(ref, "estimate_matches_imsize256", 52, 300, 400, 256)
     new_cases(ref, net)
+    round3_cases(ref)
 
 
 def new_cases(ref, net):
@@ -200,8 +214,17 @@ def new_cases(ref, net):
     case_real_pair(ref, "real_pair_3", "pair_3", 1024)
 
 
+def round3_cases(ref):
+    """Round-3 fixtures: the example photographs with the contrast checkpoint (`python -m oracle.make_golden --r3`)."""
+    case_real_pair(ref, "real_pair_1_contrast", "pair_1", None, contrast=4.0)
+    case_real_pair(ref, "real_pair_2_contrast", "pair_2", 640, contrast=4.0)
+    case_real_pair(ref, "real_pair_3_contrast", "pair_3", 1024, contrast=4.0)
+
+
 if __name__ == "__main__":
-    if "--new" in sys.argv:
+    if "--r3" in sys.argv:
+        round3_cases(load_reference())
+    elif "--new" in sys.argv:
         os.makedirs(GOLDEN, exist_ok=True)
         _sd = synthetic.make_state_dict(SD_SEED)
         new_cases(load_reference(), build_reference_net(_sd, synthetic.default_regressor_config()))

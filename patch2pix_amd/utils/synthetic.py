@@ -122,12 +122,48 @@ def _pilot_outputs(gen, sd, prefix, feat_dim, n=6):
     return F.linear(v, sd[prefix + ".fc.6.weight"], sd[prefix + ".fc.6.bias"])
 
 
-def make_state_dict(seed=0, peaky_ncn=True, backbone=True):
-    """Reference-layout state_dict (fp32 CPU tensors) from one integer seed."""
+def contrast_shift(sd, kappa=4.0, images=2, height=240, width=320):
+    """Per-channel shift [256] that makes the layer-3 features of the random-init backbone SPARSE: mean + kappa *
+    standard deviation of the last block's pre-ReLU output over a few synthetic images, rounded to 1/64.  With the plain
+    He-init backbone every feature vector of a photograph is dense and positive (mean cosine between two cells 0.95),
+    the correlation volume is nearly flat and most argmaxes of the coarse stage are undecidable in fp32; subtracting
+    the shift in the last BatchNorm (bias of `extract.layer3.5.bn2`) leaves ~20 % of the channels active per cell
+    (mean cosine 0.2-0.4).  Calibration runs the backbone on the CPU, so fixtures store the shift they were made with
+    (`make_state_dict(contrast=<tensor>)`) instead of re-deriving it on another machine."""
+    import torch.nn.functional as F
+    from ..networks import resnet
+
+    net = resnet.ResNet34()
+    net.change_stride("layer3")
+    net.load_state_dict({k[len("extract."):]: v for k, v in sd.items() if k.startswith("extract.")}, strict=False)
+    net.eval()
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+    blk, cols = net.layer3[5], []
+    with torch.no_grad():
+        for s in range(images):
+            for im in make_image_pair(900 + s, height, width):
+                t = (torch.from_numpy(im).permute(2, 0, 1).float() / 255 - mean) / std
+                x = F.relu(net.bn1(net.conv1(t[None])))
+                x = net.layer2(net.layer1(F.max_pool2d(x, 3, 2, 1)))
+                for b in net.layer3[:5]:
+                    x = b(x)
+                z = blk.bn2(blk.conv2(F.relu(blk.bn1(blk.conv1(x))))) + x
+                cols.append(z[0].reshape(z.shape[1], -1))
+    z = torch.cat(cols, dim=1)
+    return torch.round((z.mean(dim=1) + kappa * z.std(dim=1)) * 64) / 64
+
+
+def make_state_dict(seed=0, peaky_ncn=True, backbone=True, contrast=None):
+    """Reference-layout state_dict (fp32 CPU tensors) from one integer seed.  `contrast`: None (plain backbone), a
+    float kappa (calibrate `contrast_shift` here) or the [256] shift tensor of a fixture."""
     gen = torch.Generator().manual_seed(int(seed))
     sd = {}
     if backbone:
         _backbone(gen, sd)
+        if contrast is not None:
+            shift = contrast_shift(sd, float(contrast)) if isinstance(contrast, (int, float)) else torch.as_tensor(contrast).float()
+            sd["extract.layer3.5.bn2.bias"] = sd["extract.layer3.5.bn2.bias"] - shift
     _ncn(gen, sd, peaky_ncn)
     _regressor(gen, sd, "regress_mid")
     _regressor(gen, sd, "regress_fine")

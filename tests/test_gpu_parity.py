@@ -217,9 +217,9 @@ def test_fine_empty_and_single(dev, ops, weights):
 
 
 # ------------------------------------------------------------------------------------------ whole path
-def _model(dev):
+def _model(dev, contrast=None):
     from patch2pix_amd.utils.eval import model_helper
-    return model_helper.load_model(synthetic.make_checkpoint(0), lprint=lambda *a: None)
+    return model_helper.load_model(synthetic.make_checkpoint(0, contrast=contrast), lprint=lambda *a: None)
 
 
 def _near_integer_rows(mid, eps=2e-4):
@@ -323,18 +323,21 @@ def test_batched_launch_equals_per_pair(dev, ops, weights):
 # ------------------------------------------------------------------------------------------ full sizes
 def _adjudicate_delta_flips(fa, fb, got, ref_code, ksize=2):
     """Every pooled cell whose relocalisation argmax differs from the fp32 oracle's is re-evaluated in fp64: the
-    two candidates' correlations must be a genuine near-tie (gap below fp32 round-off of a 256-term dot product of
-    unit vectors), otherwise the difference is an error.  Returns [(cell, got, ref, top-2 gap)]."""
+    two candidates' correlations must be closer than the fp32 error bound of the two dot products (tests/adjudicate.py:
+    eps_256 * sum |a_i b_i| per candidate), otherwise the difference is an error.  Returns [(cell, got, ref, gap, bound)]."""
+    from adjudicate import _eps, U
     k = ksize
     na = fa.double() / (fa.double().pow(2).sum(0, keepdim=True) + 1e-6).sqrt()          # modules.py:6 in fp64
     nb = fb.double() / (fb.double().pow(2).sum(0, keepdim=True) + 1e-6).sqrt()
+    eps_c = _eps(fa.shape[0], 1.0) + 2 * (0.5 * _eps(fa.shape[0], 1.0) + 3 * U)
     out = []
     for a, b, c, d in np.argwhere(got != ref_code):
         def corr_of(code):
             di, dj, dk, dl = code // (k * k * k), (code // (k * k)) % k, (code // k) % k, code % k
-            return float((na[:, k * a + di, k * b + dj] * nb[:, k * c + dk, k * d + dl]).sum())
-        g, r = corr_of(int(got[a, b, c, d])), corr_of(int(ref_code[a, b, c, d]))
-        out.append(((int(a), int(b), int(c), int(d)), int(got[a, b, c, d]), int(ref_code[a, b, c, d]), abs(g - r)))
+            va, vb = na[:, k * a + di, k * b + dj], nb[:, k * c + dk, k * d + dl]
+            return float((va * vb).sum()), eps_c * float((va * vb).abs().sum())
+        (g, eg), (r, er) = corr_of(int(got[a, b, c, d])), corr_of(int(ref_code[a, b, c, d]))
+        out.append(((int(a), int(b), int(c), int(d)), int(got[a, b, c, d]), int(ref_code[a, b, c, d]), abs(g - r), eg + er))
     return out
 
 
@@ -352,9 +355,9 @@ def test_coarse_full_size_vs_oracle(dev, ops, cweights):
     ref_code = (((rd[0] * 2 + rd[1]) * 2 + rd[2]) * 2 + rd[3]).numpy()
     flips = _adjudicate_delta_flips(p1[4], p2[4], got, ref_code)
     print(f"\n{len(flips)} of {got.size} relocalisation argmaxes differ from the fp32 oracle:")
-    for cell, g, r, gap in flips:
-        print(f"  cell {cell}: kernel {g}, oracle {r}, fp64 gap of the two candidates {gap:.3e}")
-        assert gap < 5e-7, f"cell {cell}: argmax differs but the candidates are {gap:.3e} apart in fp64 (not a near-tie)"
+    for cell, g, r, gap, bound in flips:
+        print(f"  cell {cell}: kernel {g}, oracle {r}, fp64 gap of the two candidates {gap:.3e} (fp32 error bound {bound:.1e})")
+        assert gap <= bound, f"cell {cell}: argmax differs but the candidates are {gap:.3e} apart in fp64 (bound {bound:.1e}: not a near-tie)"
     assert len(flips) <= 8
     rm, rs = orc.cal_coarse_matches(rc, rd, 2, 8)
     m, s = ops.coarse_matches(corr, delta, 2, 8, True)
@@ -411,11 +414,10 @@ def test_benched_batch_path_vs_oracle(mode, dev):
         ticket = net.coarse_async(f1, f2, ksize=2)
         fine, fine_s, mid, mid_s, coarse = net.fine_from_ticket(ticket, 0.0, True, return_all=True, ptmax=ptmax)
     torch.cuda.synchronize()
-    from adjudicate import differing_rows_are_near_ties
+    from adjudicate import ErrorModel, differing_rows_are_near_ties
     rng = np.random.RandomState(99)                     # the product draws from the global numpy RNG, pair after pair
     worst = dict(mid=0.0, fine=0.0, score=0.0)
     near_ties = 0
-    n64 = None
     with torch.no_grad():
         for b in range(B if mode == MODES[0] else 3):   # all 16 pairs in the default mode, 3 in the others (CPU time)
             rc, rd = orc.coarse_forward(pairs[b][0][4], pairs[b][1][4], 2, o_ncn)
@@ -425,13 +427,13 @@ def test_benched_batch_path_vs_oracle(mode, dev):
             if torch.equal(got_rows, rm):
                 assert torch.equal(coarse[b].cpu(), cm), f"pair {b}: sampled proposals differ"
             else:
-                # a differing row must be a near-tie in an fp64 evaluation (tests/adjudicate.py); the proposals then
-                # differ legitimately and the fine stage is compared on the kernel's own proposals
-                if n64 is None:
-                    n64, _, _ = orc.split_params(ckpt_sd, torch.float64)
-                c64, _ = orc.coarse_forward(pairs[b][0][4].double(), pairs[b][1][4].double(), 2, n64)
-                nd, gap = differing_rows_are_near_ties(got_rows, rm, c64, feats=(pairs[b][0][4], pairs[b][1][4]))
-                print(f"\npair {b}: {nd} of {rm.shape[0]} coarse rows differ from the fp32 oracle, near-ties in fp64 (gap {gap:.1e})")
+                # a differing row must be undecidable in fp32: the two candidates closer in fp64 than the error bound of an
+                # fp32 evaluation (tests/adjudicate.py); the proposals then differ legitimately and the fine stage is
+                # compared on the kernel's own proposals
+                em = ErrorModel(pairs[b][0][4], pairs[b][1][4], ckpt_sd, 2)
+                em.check(rc, "oracle fp32 volume")
+                nd, gap = differing_rows_are_near_ties(got_rows, rm, em)
+                print(f"\npair {b}: {nd} of {rm.shape[0]} coarse rows differ from the fp32 oracle, fp64 gap {gap:.3f} of the fp32 error bound")
                 near_ties += nd
                 cm = coarse[b].cpu()
             ref_mid, ref_mp, _ = orc.fine_level(pairs[b][0][:4], pairs[b][1][:4], cm, mid_p)
@@ -697,23 +699,30 @@ def test_model_helper_refine_matches_on_files(dev, tmp_path):
     assert none1 is None and none2 is None and only.shape == (3, 4)
 
 
-REAL_PAIRS = [("real_pair_1", None), ("real_pair_2", 640), ("real_pair_3", 1024)]
+REAL_PAIRS = [("real_pair_1", None), ("real_pair_2", 640), ("real_pair_3", 1024),
+              ("real_pair_1_contrast", None), ("real_pair_2_contrast", 640), ("real_pair_3_contrast", 1024)]
 
 
 @pytest.mark.parametrize("name,imsize", REAL_PAIRS)
 def test_real_image_pairs(name, imsize, dev, capsys):
-    """The reference's three example pairs (real photographs).  (1) HIP path vs CPU oracle on IDENTICAL pyramids
-    (this implementation's backbone run on the CPU): coarse rows exact, coordinates within 1e-3 px.  (2) The
-    drop-in entry estimate_matches (backbone on MIOpen) against the unmodified reference's output recorded in
-    tests/golden/real_pair_*.npz: agreement statistics incl. the fraction of matches within 3 px (MMA@3px-style,
-    reference output as ground truth); MIOpen-vs-CPU backbone round-off can flip a coarse argmax, so (2) is a report
-    with loose bars while (1) is the strict one."""
+    """The reference's three example pairs (real photographs), two checkpoints: the plain random-init one (dense positive
+    features, nearly flat volume: the near-tie stress case) and the `_contrast` one whose backbone yields sparse features
+    (synthetic.contrast_shift) so that the argmaxes of a photograph are decidable wherever the image content allows it
+    (pair_2 is a night shot: 41 % / 73 % black pixels, a third of its feature cells have an identical twin).
+    (1) HIP path vs CPU oracle vs the unmodified reference's rows on IDENTICAL pyramids (this implementation's backbone
+    run on the CPU; drift vs the reference's features is recorded): every row that is decidable in fp32 (fp64 margin above
+    the error bound of both candidates, tests/adjudicate.py) must hold the fp64 winner, every differing row must be
+    undecidable; the contrast fixtures of pair_1 and pair_3 must have NO differing row at all.  Regressed coordinates
+    within 1e-3 px on identical proposals.
+    (2) The drop-in entry estimate_matches (backbone on MIOpen) against the reference's recorded output."""
     import os
     from patch2pix_amd.utils.datasets.preprocess import load_im_flexible
     from patch2pix_amd.utils.eval import model_helper
+    from adjudicate import ErrorModel, assert_decidable_rows, differing_rows_are_near_ties
     g = gu.load(name)
+    contrast = torch.from_numpy(g["contrast_shift"]) if "contrast_shift" in g else None
     d = os.path.join(gu.GOLDEN, "images", str(g["pair"]))
-    net = _model(dev)
+    net = _model(dev, contrast)
     t1, s1 = load_im_flexible(os.path.join(d, "1.jpg"), 2, net.upsample, imsize=imsize)
     t2, s2 = load_im_flexible(os.path.join(d, "2.jpg"), 2, net.upsample, imsize=imsize)
     # (1) identical pyramids on both sides
@@ -725,20 +734,39 @@ def test_real_image_pairs(name, imsize, dev, capsys):
     finally:
         net.extract.to(dev)
     drift = abs(gu.checksum([pyr1[4][None]]) - float(g["feat1_checksum"])) / float(g["feat1_checksum"])
-    from adjudicate import differing_rows_are_near_ties
-    sd = gu.state_dict(0)
+    sd = gu.state_dict(0) if contrast is None else synthetic.make_state_dict(0, contrast=contrast)
     with torch.no_grad():
         f1, f2 = [f[None].to(dev) for f in pyr1], [f[None].to(dev) for f in pyr2]
         ticket = net.coarse_async(f1, f2, ksize=2)
         fine, fine_s, mid, mid_s, coarse = net.fine_from_ticket(ticket, 0.0, True, return_all=True)
         o_ncn, mid_p, fine_p = orc.split_params(sd)
-        n64, _, _ = orc.split_params(sd, torch.float64)
         rc, rd = orc.coarse_forward(pyr1[4], pyr2[4], 2, o_ncn)
         rm, rs = orc.cal_coarse_matches(rc, rd, 2, 8)
-        c64, _ = orc.coarse_forward(pyr1[4].double(), pyr2[4].double(), 2, n64)
-    # with the random-init checkpoint the consensus volume of a real pair is nearly flat: a differing row must be a
-    # near-tie in the fp64 volume (tests/adjudicate.py); everything else must be equal
-    nflip, worst = differing_rows_are_near_ties(ticket["matches"][0].cpu(), rm, c64, feats=(pyr1[4], pyr2[4]))
+    got_rows = ticket["matches"][0].cpu()
+    lists = {"oracle": rm}
+    if "all_rows" in g:
+        lists["reference"] = torch.from_numpy(g["all_rows"].astype(np.int64))
+    ndiff = {k: int((got_rows != v).any(dim=1).sum()) for k, v in lists.items()}
+    expect_exact = name in ("real_pair_1_contrast", "real_pair_3_contrast")
+    report = f"{name}: identical pyramids (feature drift vs the reference's CPU run {drift:.1e}): coarse rows differing from " + \
+        ", ".join(f"the {k} {n} of {rm.shape[0]}" for k, n in ndiff.items())
+    if expect_exact:
+        assert all(n == 0 for n in ndiff.values()), report
+    if any(ndiff.values()) or name in ("real_pair_1", "real_pair_1_contrast", "real_pair_2_contrast"):
+        # the error model costs minutes of CPU at 1024 px: built where a row differs and for the two smaller contrast pairs
+        em = ErrorModel(pyr1[4], pyr2[4], sd, 2)
+        slack = em.check(rc, "oracle fp32 volume")
+        with torch.no_grad():
+            corr_gpu, _ = net.forward_coarse_match(f1[4], f2[4], ksize=2)
+        slack_gpu = em.check(corr_gpu[0, 0].cpu(), "HIP volume")
+        ndec, nrows = assert_decidable_rows(got_rows, em)
+        worst = 0.0
+        for k, v in lists.items():
+            _, w = differing_rows_are_near_ties(got_rows, v, em)
+            worst = max(worst, w)
+        report += (f"; {ndec} of {nrows} rows decidable in fp32, all equal to the fp64 winner; every differing row undecidable "
+                   f"(worst fp64 gap {worst:.3f} of the fp32 error bound; |error| of the oracle / HIP volume {slack:.3f} / "
+                   f"{slack_gpu:.3f} of the bound)")
     # fine stage on the kernel's own proposals against the oracle (identical pyramids, identical proposals)
     with torch.no_grad():
         ref_mid, ref_mp, _ = orc.fine_level(pyr1[:4], pyr2[:4], coarse[0].cpu(), mid_p)
@@ -747,8 +775,7 @@ def test_real_image_pairs(name, imsize, dev, capsys):
     _compare_matches(fine[0].cpu(), ref_fine)
     assert (mid_s[0].cpu() - ref_mp).abs().max() <= SCORE_TOL and (fine_s[0].cpu() - ref_fp).abs().max() <= SCORE_TOL
     with capsys.disabled():
-        print(f"\n{name}: identical pyramids: {nflip} of {rm.shape[0]} coarse rows differ from the fp32 oracle, all near-ties "
-              f"(worst fp64 gap {worst:.1e}); {coarse[0].shape[0]} proposals: max |d mid| {(mid[0].cpu() - ref_mid).abs().max():.2e} px, "
+        print(f"\n{report}; {coarse[0].shape[0]} proposals: max |d mid| {(mid[0].cpu() - ref_mid).abs().max():.2e} px, "
               f"|d fine| {(fine[0].cpu() - ref_fine).abs().max():.2e} px")
     # (2) the entry point on the files, against the reference's recorded output
     m, s, c = model_helper.estimate_matches(net, os.path.join(d, "1.jpg"), os.path.join(d, "2.jpg"), ksize=2, io_thres=0.25,
@@ -761,12 +788,14 @@ def test_real_image_pairs(name, imsize, dev, capsys):
         err = np.abs(m[gi] - g["fine_matches"][ri]).max(axis=1)
         mma3 = float((err < 3.0).mean() * frac)
         with capsys.disabled():
-            print(f"\n{name}: backbone-on-CPU feature drift vs golden {drift:.1e}; {len(c)} matches, reference {len(g['fine_coarse'])}; "
-                  f"{frac:.3f} of the reference's coarse matches reproduced; of those: median |d| {np.median(err):.2e} px, "
+            print(f"{name}: entry point (backbone on MIOpen): {len(c)} matches, reference {len(g['fine_coarse'])}; "
+                  f"{frac:.3f} of the reference's coarse matches reproduced; of those: median |d| {np.median(err):.2e} px, max {err.max():.2e} px, "
                   f"within 1e-3 px {float((err < 1e-3).mean()):.3f}, within 3 px {float((err < 3).mean()):.3f}; "
                   f"MMA@3px-style agreement (reference = ground truth) {mma3:.3f}")
-        assert np.median(err) < 0.05
-    assert frac >= 0.7
+        assert np.median(err) < (1e-3 if contrast is not None else 0.05)
+        if expect_exact:
+            assert float((err < 1e-3).mean()) >= 0.99 and mma3 >= 0.99
+    assert frac >= (0.99 if expect_exact else 0.7)
 
 
 def test_config_E_vs_oracle(dev, ops, cweights):

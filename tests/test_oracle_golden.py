@@ -131,3 +131,44 @@ def test_real_image_pairs(name, imsize):
     err = np.abs(fine[gi] - g["fine_matches"][ri]).max(axis=1)
     assert err[stable].max() < 2e-3 and (~stable).sum() <= 2
     np.testing.assert_allclose(out["fine_scores"].numpy()[keep][gi][stable], g["fine_scores"][ri][stable], atol=1e-5)
+
+
+@pytest.mark.parametrize("name,imsize", [("real_pair_1_contrast", None), ("real_pair_2_contrast", 640)])
+def test_real_image_pairs_contrast_checkpoint(name, imsize):
+    """The example photographs with the contrast checkpoint (sparse backbone features, synthetic.contrast_shift; the
+    shift the fixture was made with is stored in it): the oracle's coarse rows against ALL rows the unmodified reference
+    produced (before filter_coarse).  pair_1: every row equal.  pair_2 (night shot, a third of its cells have an
+    identical twin): the rows that differ must be undecidable in fp32 -- the two candidates closer in fp64 than the
+    error bound of an fp32 evaluation (tests/adjudicate.py) --, every decidable row of both lists must hold the fp64
+    winner, and the oracle's fp32 volume must lie inside the error model (which validates the model on real data)."""
+    import os
+    from adjudicate import ErrorModel, assert_decidable_rows, differing_rows_are_near_ties
+    from patch2pix_amd.networks import resnet
+    from patch2pix_amd.utils import synthetic
+    from patch2pix_amd.utils.datasets.preprocess import load_im_flexible
+    g = gu.load(name)
+    sd = synthetic.make_state_dict(int(g["sd_seed"]), contrast=torch.from_numpy(g["contrast_shift"]))
+    d = os.path.join(gu.GOLDEN, "images", str(g["pair"]))
+    t1, _ = load_im_flexible(os.path.join(d, "1.jpg"), 2, 8, imsize=imsize)
+    t2, _ = load_im_flexible(os.path.join(d, "2.jpg"), 2, 8, imsize=imsize)
+    net = resnet.ResNet34()
+    net.change_stride("layer3")
+    net.load_state_dict({k[len("extract."):]: v for k, v in sd.items() if k.startswith("extract.")}, strict=False)
+    net.eval()
+    ncn, _, _ = orc.split_params(sd)
+    with torch.no_grad():
+        fa, fb = net.pyramid(t1[None])[4][0], net.pyramid(t2[None])[4][0]
+        assert abs(gu.checksum([fa[None]]) - float(g["feat1_checksum"])) <= 1e-5 * float(g["feat1_checksum"])
+        corr, delta = orc.coarse_forward(fa, fb, 2, ncn)
+        rows, _ = orc.cal_coarse_matches(corr, delta, 2, 8)
+        ref_rows = torch.from_numpy(g["all_rows"].astype(np.int64))
+        ndiff = int((rows != ref_rows).any(dim=1).sum())
+        if name == "real_pair_1_contrast":
+            assert ndiff == 0
+        em = ErrorModel(fa, fb, sd, 2)
+        assert em.check(corr, "oracle fp32 volume") < 0.25        # measured 0.05: the bound is conservative, not vacuous
+        nd, worst = differing_rows_are_near_ties(rows, ref_rows, em)
+        n_dec, n = assert_decidable_rows(rows, em)
+        assert assert_decidable_rows(ref_rows, em)[0] == n_dec
+    assert nd == ndiff and nd <= 16 and n_dec >= 0.4 * n
+    print(f"\n{name}: {nd} of {n} rows differ between oracle and reference (fp64 gap <= {worst:.3f} of the bound); {n_dec} decidable")
