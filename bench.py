@@ -15,7 +15,11 @@ The headline (`value`, `dtype`, `roofline`) is measured in the library's default
 fp32-equivalent (bf16x3: every fp32 operand as three bf16 planes = 24 significant bits, fp32 accumulation;
 see include/p2p_hip.h).  Outside the timed region rank 0 also (i) pushes one of the benched pairs -- through the
 same batched calls -- and the CPU oracle and reports the differences (`parity`), (ii) times the other
-arithmetic modes for a few steps (`other_modes`, informational), (iii) times the oracle on the host (`cpu_baseline`).
+arithmetic modes for a few steps (`other_modes`, informational), (iii) times BASELINE configs[4] for a few steps
+(`other_configs.E`: 960x1280, ptmax 800 x panc 8 -- GPU legs only), (iv) times the oracle on the host (`cpu_baseline`).
+
+  python bench.py --pairs 10000 [--gpus N]     BASELINE configs[3]: a stream of seeded pairs, pair i on rank i % N,
+                                                strong scaling (`scaling_efficiency` against rank 0 running alone)
 """
 import argparse
 import hashlib
@@ -77,6 +81,10 @@ def parse():
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run oracle check of a benched pair")
     ap.add_argument("--no-other-modes", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end estimate_matches timing")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the config-E leg of the default run")
+    ap.add_argument("--pairs", type=int, default=0,
+                    help="stream mode (BASELINE configs[3]): this many seeded pairs in total, sharded pair_id %% world, "
+                         "generated on the device chunk by chunk; --steps / --warmup are ignored")
     return ap.parse_args()
 
 
@@ -128,38 +136,262 @@ def cpu_baseline(ckpt, pyr1, pyr2, cfg):
                       f"torch {torch.__version__}"}
 
 
-def parity_check(net, ckpt, batch, cpu_pair, cfg):
-    """Push one benched pair through the SAME batched calls bench times (coarse_async / fine_from_ticket over the
-    whole batch) and through the CPU oracle: coarse rows bit-exact?, regressed coordinates / scores max |diff|.
-    The fine level of the oracle is fed the kernel's own mid matches (a 1e-6 px wobble across an integer would move
-    the whole fine patch by one pixel, networks/utils.py:19); `fine_px_chain` is the plain end-to-end difference."""
+def parity_check(net, ckpt, batch, cpu_pairs, cfg, pairs=None):
+    """Push the benched batch through the SAME batched calls bench times (coarse_async / fine_from_ticket over the
+    whole batch) and every pair of it (the first `pairs` of them) through the CPU oracle: coarse rows bit-exact?,
+    sampled proposals equal?, regressed coordinates / scores max |diff|.  The fine level of the oracle is fed the
+    kernel's own mid matches (a 1e-6 px wobble across an integer would move the whole fine patch by one pixel,
+    networks/utils.py:19); `max_px_err_fine_chain` is the plain end-to-end difference (pair 0).  The product samples the
+    ptmax proposals pair after pair from the global numpy RNG (networks/utils.py:55-63), the oracle from an equally
+    seeded stream in the same order; where a coarse row differs (an fp32 near-tie, tests/adjudicate.py) the proposals
+    differ legitimately and the fine stage of that pair is compared on the kernel's own proposals."""
+    from oracle import p2p_oracle as orc
     seed = 4242
-    np.random.seed(seed)                       # pair 0 is the first one filter_coarse samples for
+    np.random.seed(seed)
+    rng = np.random.RandomState(seed)
     f1, f2 = batch
+    B = f1[0].shape[0] if pairs is None else min(pairs, f1[0].shape[0])
+    ncn, mid_p, fine_p = orc.split_params(ckpt["state_dict"])
     with torch.no_grad():
         ticket = net.coarse_async(f1, f2, ksize=KSIZE)
         fine, fine_s, mid, mid_s, coarse = net.fine_from_ticket(ticket, ncn_thres=0.0, mutual=True, return_all=True,
                                                                 ptmax=cfg["ptmax"])
         torch.cuda.synchronize()
-        all_rows = ticket["matches"][0].cpu()
-        g_mid = mid[0].cpu()
-        ref = oracle_pair(ckpt, cpu_pair[0], cpu_pair[1], cfg["ptmax"], cfg["panc"], seed, gpu_mid=g_mid)
-        ref_chain = oracle_pair(ckpt, cpu_pair[0], cpu_pair[1], cfg["ptmax"], cfg["panc"], seed)
-    rows_equal = bool(torch.equal(all_rows, ref["all_rows"]))
-    props_equal = bool(torch.equal(coarse[0].cpu(), ref["proposals"]))
-    out = {"pair": "pair 0 of the benched batch, batched calls", "coarse_indices_equal": rows_equal,
-           "coarse_rows": int(all_rows.shape[0]),
-           "coarse_rows_differing": int((all_rows != ref["all_rows"]).any(dim=1).sum()),
-           "proposals_equal": props_equal, "proposals": int(coarse[0].shape[0])}
-    if props_equal:
-        out.update({
-            "max_px_err_mid": float((g_mid - ref["mid"]).abs().max()),
-            "max_px_err": float((fine[0].cpu() - ref["fine"]).abs().max()),
-            "max_score_err": float(max((mid_s[0].cpu() - ref["mid_scores"]).abs().max(),
-                                       (fine_s[0].cpu() - ref["fine_scores"]).abs().max())),
-            "max_px_err_fine_chain": float((fine[0].cpu() - ref_chain["fine"]).abs().max()),
-            "tolerance_px": 1e-3, "tolerance_score": 1e-5})
+        out = {"pairs_checked": B, "what": f"the first {B} pairs of the benched batch, through the batched calls the bench times",
+               "coarse_rows": 0, "coarse_rows_differing": 0, "pairs_with_differing_rows": 0, "proposals": 0,
+               "pairs_with_equal_proposals": 0, "max_px_err_mid": 0.0, "max_px_err": 0.0, "max_score_err": 0.0}
+        for b in range(B):
+            p1, p2 = cpu_pairs[b]
+            corr, delta = orc.coarse_forward(p1[4], p2[4], KSIZE, ncn)
+            rows, sc = orc.cal_coarse_matches(corr, delta, KSIZE, 8)
+            cm, _ = orc.filter_coarse(rows, sc, 0.0, True, ptmax=cfg["ptmax"], rng=rng)
+            cm = orc.shift_to_anchors(cm, 8, cfg["panc"])
+            got_rows, got_props, g_mid = ticket["matches"][b].cpu(), coarse[b].cpu(), mid[b].cpu()
+            ndiff = int((got_rows != rows).any(dim=1).sum())
+            out["coarse_rows"] += int(rows.shape[0])
+            out["coarse_rows_differing"] += ndiff
+            out["pairs_with_differing_rows"] += int(ndiff > 0)
+            out["proposals"] += int(got_props.shape[0])
+            same = bool(torch.equal(got_props, cm))
+            out["pairs_with_equal_proposals"] += int(same)
+            props = cm if same else got_props
+            r_mid, r_ms, _ = orc.fine_level(p1[:4], p2[:4], props, mid_p)
+            r_fine, r_fs, _ = orc.fine_level(p1[:4], p2[:4], g_mid, fine_p)
+            out["max_px_err_mid"] = max(out["max_px_err_mid"], float((g_mid - r_mid).abs().max()))
+            out["max_px_err"] = max(out["max_px_err"], float((fine[b].cpu() - r_fine).abs().max()))
+            out["max_score_err"] = max(out["max_score_err"], float((mid_s[b].cpu() - r_ms).abs().max()),
+                                       float((fine_s[b].cpu() - r_fs).abs().max()))
+            if b == 0:
+                chain, _, _ = orc.fine_level(p1[:4], p2[:4], r_mid, fine_p)
+                out["max_px_err_fine_chain"] = float((fine[0].cpu() - chain).abs().max())
+    out["coarse_indices_equal"] = out["coarse_rows_differing"] == 0
+    out["proposals_equal"] = out["pairs_with_equal_proposals"] == B
+    out.update({"tolerance_px": 1e-3, "tolerance_score": 1e-5})
     return out
+
+
+def roofline_of(mode, events):
+    M = MODES[mode]
+    kern_ms = [a.elapsed_time(b) for a, b, _, _ in events]
+    flop = sum(n * lv * FLOP_PER_PROPOSAL_LEVEL for _, _, n, lv in events) / max(len(events), 1)
+    avg_ms = sum(kern_ms) / max(len(kern_ms), 1)
+    # achieved = ALGORITHMIC flop of one regress launch (SURVEY 8d: 608.3 MFLOP per proposal and level) / its
+    # average duration (HIP events on the launch stream)
+    achieved = flop / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    return {"kernel": M["kernel"], "bound": "mfma", "achieved": achieved, "peak": M["peak"], "unit": "TFLOP/s",
+            "frac": achieved / M["peak"], "traffic": None, "avg_launch_ms": avg_ms, "algorithmic_flop_per_launch": flop,
+            "peak_note": M["peak_note"],
+            "note": "achieved = algorithmic flop of the launch (608.3 MFLOP x proposals x levels) / launch time "
+                    "measured with HIP events on the launch stream"}
+
+
+def add_traffic(roof, mode, config, proposals_per_launch):
+    """HBM traffic of the dominant kernel: PMC measurement (tools/collect_profiles.sh) of THIS source tree, same kernel,
+    configuration and launch size -- otherwise it stays null."""
+    tf = os.path.join(ROOT, "profiles", "regress_traffic.json")
+    if not os.path.exists(tf):
+        return
+    rec = json.load(open(tf)).get(mode if config == "A" else f"{mode}@{config}", {})
+    if (rec.get("kernel") == MODES[mode]["kernel"] and rec.get("proposals_per_launch") == proposals_per_launch
+            and rec.get("config", "A") == config and rec.get("source_hash") == source_hash()):
+        roof["traffic"] = rec.get("hbm_bytes_per_launch")
+        roof["traffic_source"] = rec.get("source")
+        roof["traffic_note"] = ("FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE of the kernel per launch = requests on the "
+                                "L2's fabric side: Infinity-Cache hits are included, so this is an upper bound of the HBM "
+                                "bytes; the compulsory bytes of a 16-pair launch are ~1 GB (16 x 61 MB of pyramids + 57 MB of "
+                                "weights), the rest are L2 capacity misses of the 28.5 MB-per-level weight stream, which "
+                                "lives in the 256 MB Infinity Cache")
+
+
+class Runner:
+    """The benched loop over resident batches: `run(n)` = n steps, software-pipelined on one stream (the coarse stage of
+    step i+1 is enqueued before the host samples the proposals of step i, so the GPU never waits for the host)."""
+
+    def __init__(self, net, batches, ptmax, overlap=False):
+        self.net, self.batches, self.ptmax = net, batches, ptmax
+        self.coarse_stream = torch.cuda.Stream(device=net.device) if overlap else None
+
+    def submit(self, i):
+        f1, f2 = self.batches[i % len(self.batches)]
+        if self.coarse_stream is None:
+            return self.net.coarse_async(f1, f2, ksize=KSIZE)
+        # experiment: the coarse stage of the NEXT step on its own stream, beside the regress launch of the current one
+        with torch.cuda.stream(self.coarse_stream):
+            return self.net.coarse_async(f1, f2, ksize=KSIZE)
+
+    def finish(self, ticket):
+        return self.net.fine_from_ticket(ticket, ncn_thres=0.0, mutual=True, ptmax=self.ptmax)
+
+    def run(self, nsteps):
+        out = []
+        ticket = self.submit(0)
+        for i in range(nsteps):
+            nxt = self.submit(i + 1) if i + 1 < nsteps else None
+            out.append(self.finish(ticket))
+            ticket = nxt
+        return out
+
+
+def resident_batches(cfg, rank, dev, nbatches, on_device=False):
+    """`nbatches` distinct synthetic batches of cfg['pairs_per_step'] pairs, resident in HBM; the CPU copies are kept for
+    the oracle legs (on_device: generated on the GPU, no CPU copy -- legs without an oracle)."""
+    from patch2pix_amd.utils import synthetic
+    B, H, W = cfg["pairs_per_step"], cfg["H"], cfg["W"]
+    if on_device:
+        cpu_pairs = None
+        pairs = [synthetic.make_correlated_pyramids_device(1000 + rank * 64 + i, H, W, dev) for i in range(nbatches * B)]
+    else:
+        pairs = cpu_pairs = [synthetic.make_correlated_pyramids(1000 + rank * 64 + i, H, W) for i in range(nbatches * B)]
+    batches = []
+    for k in range(nbatches):
+        chunk = pairs[k * B:(k + 1) * B]
+        batches.append(([torch.stack([p[0][j] for p in chunk]).to(dev) for j in range(5)],
+                        [torch.stack([p[1][j] for p in chunk]).to(dev) for j in range(5)]))
+    return cpu_pairs, batches
+
+
+def coarse_stage_ms(net, batch, reps=3):
+    """Per-pair time of the coarse stage alone (forward_coarse_match + cal_coarse_matches), HIP events on the launch stream."""
+    f1, f2 = batch
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    with torch.no_grad():
+        corr, delta = net.forward_coarse_match(f1[4], f2[4], ksize=KSIZE)
+        torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(reps):
+            corr, delta = net.forward_coarse_match(f1[4], f2[4], ksize=KSIZE)
+            net.cal_coarse_matches(corr, delta, ksize=KSIZE, upsample=net.upsample, center=True)
+        ev[1].record()
+        torch.cuda.synchronize()
+    return ev[0].elapsed_time(ev[1]) / reps / f1[4].shape[0]
+
+
+def config_leg(net, name, mode, rank, dev, steps=3, warmup=1):
+    """A short GPU-only measurement of another BASELINE configuration with the same loop (no oracle, no CPU legs)."""
+    from patch2pix_amd import ops
+    cfg = dict(CONFIGS[name])
+    panc0 = net.panc
+    net.panc = cfg["panc"]
+    try:
+        _, batches = resident_batches(cfg, rank, dev, 1, on_device=True)
+        r = Runner(net, batches, cfg["ptmax"])
+        np.random.seed(4321)
+        with torch.no_grad():
+            r.run(warmup)
+            torch.cuda.synchronize()
+            ops.regress_events = []
+            t0 = time.perf_counter()
+            r.run(steps)
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            events, ops.regress_events = ops.regress_events, None
+        roof = roofline_of(mode, events)
+        add_traffic(roof, mode, name, cfg["pairs_per_step"] * cfg["ptmax"] * cfg["panc"])
+        coarse_ms = coarse_stage_ms(net, batches[0])
+        B = cfg["pairs_per_step"]
+        return {"workload": cfg["workload"], "value": steps * B / elapsed, "unit": "pairs/s", "steps": steps, "warmup": warmup,
+                "pairs_per_step": B, "ms_per_step": elapsed / steps * 1e3, "regress_mode": mode,
+                "coarse_stage_ms_per_pair": coarse_ms, "regress_launch_ms": roof["avg_launch_ms"],
+                "roofline": {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms",
+                                                 "algorithmic_flop_per_launch")},
+                "data": "synthetic (pyramids generated on the device), no oracle leg: parity at this size is "
+                        "tests/test_gpu_parity.py::test_config_E_vs_oracle"}
+    finally:
+        net.panc = panc0
+        del batches
+        torch.cuda.empty_cache()
+
+
+def stream_mode(args, net, cfg, mode, rank, world, dev, dist):
+    """BASELINE configs[3]: `--pairs N` seeded pairs, pair i on rank i % world, each chunk's pyramids generated on the
+    device from the pair ids (10 000 x 71 MB cannot be resident), results exchanged every 8 chunks.  Strong scaling:
+    total work fixed; `scaling_efficiency` = value / (world x the rate of rank 0 running ALONE on a few chunks of the same
+    stream before the timed region)."""
+    from patch2pix_amd.gather import run_pair_stream
+    from patch2pix_amd.utils import synthetic
+    H, W, B, PTMAX = cfg["H"], cfg["W"], cfg["pairs_per_step"], cfg["ptmax"]
+
+    def submit(pair_ids):
+        pairs = [synthetic.make_correlated_pyramids_device(pid, H, W, dev) for pid in pair_ids]
+        f1 = [torch.stack([p[0][j] for p in pairs]) for j in range(5)]
+        f2 = [torch.stack([p[1][j] for p in pairs]) for j in range(5)]
+        t = net.coarse_async(f1, f2, ksize=KSIZE)
+        t["ids"] = pair_ids
+        return t
+
+    def finish(ticket):
+        np.random.seed(ticket["ids"][0])          # the ptmax sample of a chunk depends on its pair ids only, not on the sharding
+        return net.fine_from_ticket(ticket, ncn_thres=0.0, mutual=True, ptmax=PTMAX)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < 1.5:                      # clocks / allocator / page cache (see main)
+            run_pair_stream(2 * B, 0, 1, B, submit, finish, exchange=False)
+            torch.cuda.synchronize()
+        barrier()
+        solo = None
+        if rank == 0:                                                  # single-GPU reference: rank 0 alone, the others idle
+            n_solo = min(args.pairs, 6 * B)
+            t0 = time.perf_counter()
+            run_pair_stream(n_solo, 0, 1, B, submit, finish, exchange=False)
+            torch.cuda.synchronize()
+            solo = n_solo / (time.perf_counter() - t0)
+        barrier()
+        t0 = time.perf_counter()
+        rows, ids, mine = run_pair_stream(args.pairs, rank, world, B, submit, finish, gather_every=8, device=dev)
+        torch.cuda.synchronize()
+        busy = time.perf_counter() - t0
+        barrier()
+        elapsed = time.perf_counter() - t0
+    assert int(torch.unique(ids).numel()) == args.pairs and int(rows.shape[0]) == args.pairs * PTMAX * cfg["panc"]
+    per_rank = [mine / busy]
+    if dist is not None:
+        t = torch.tensor([elapsed, mine / busy], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        elapsed = max(float(x[0]) for x in allt)
+        per_rank = [float(x[1]) for x in allt]
+    if rank != 0:
+        return None
+    value = args.pairs / elapsed
+    return {"metric": f"image-pairs/sec ({H}x{W}, ptmax={PTMAX}), matching hot path over a stream of {args.pairs} seeded pairs",
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": -(-args.pairs // (B * world)), "warmup": 0,
+            "ms_per_step": elapsed / max(1, -(-args.pairs // (B * world))) * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": MODES[mode]["dtype"], "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[3]: stream of {args.pairs} seeded {H}x{W} pairs (pyramids generated on the "
+                                   f"device from the pair id, chunk by chunk), pair i on rank i % {world}, {B} pairs per chunk, "
+                                   f"ptmax={PTMAX}; match arrays exchanged every 8 chunks (RCCL all_gather)",
+                       "pairs": args.pairs, "pairs_per_step": B, "regress_mode": mode,
+                       "parallelism": f"pair_id % {world}, no data-path collective"},
+            "per_rank_pairs_per_s": per_rank, "single_gpu_reference_pairs_per_s": solo,
+            "scaling_efficiency": value / (world * solo) if solo else None,
+            "note": "a step here = one chunk per rank; the timed region includes the on-device generation of every chunk's "
+                    "pyramids (the stand-in for the backbone producer) and every exchange"}
 
 
 def main():
@@ -195,40 +427,20 @@ def main():
         for w in net._weights()[1:]:
             w.set_mode(args.mode)
     mode = net._weights()[1].mode
+
+    if args.pairs:
+        out = stream_mode(args, net, cfg, mode, rank, world, dev, dist)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
     # a few distinct synthetic batches per rank, resident in HBM before the clock starts
-    nbatches = 2
-    cpu_pairs = [synthetic.make_correlated_pyramids(1000 + rank * 64 + i, H, W) for i in range(nbatches * B)]
-    batches = []
-    for k in range(nbatches):
-        chunk = cpu_pairs[k * B:(k + 1) * B]
-        f1 = [torch.stack([p[0][j] for p in chunk]).to(dev) for j in range(5)]
-        f2 = [torch.stack([p[1][j] for p in chunk]).to(dev) for j in range(5)]
-        batches.append((f1, f2))
+    cpu_pairs, batches = resident_batches(cfg, rank, dev, 2)
     np.random.seed(1234 + rank)
-
-    coarse_stream = torch.cuda.Stream(device=dev) if args.overlap else None
-
-    def submit(i):
-        f1, f2 = batches[i % nbatches]
-        if coarse_stream is None:
-            return net.coarse_async(f1, f2, ksize=KSIZE)
-        # experiment: the coarse stage of the NEXT step on its own stream, beside the regress launch of the current one
-        with torch.cuda.stream(coarse_stream):
-            return net.coarse_async(f1, f2, ksize=KSIZE)
-
-    def finish(ticket):
-        return net.fine_from_ticket(ticket, ncn_thres=0.0, mutual=True, ptmax=PTMAX)
-
-    def run(nsteps):
-        """nsteps steps, software-pipelined on one stream: the coarse stage of step i+1 is enqueued
-        before the host filters step i, so the GPU never waits for the host."""
-        out = []
-        ticket = submit(0)
-        for i in range(nsteps):
-            nxt = submit(i + 1) if i + 1 < nsteps else None
-            out.append(finish(ticket))
-            ticket = nxt
-        return out
+    runner = Runner(net, batches, PTMAX, overlap=bool(args.overlap))
+    run = runner.run
 
     def barrier():
         if dist is not None:
@@ -243,7 +455,7 @@ def main():
         nrows = None
         if with_gather:
             # final gather of the match arrays (the only inter-GPU exchange of the path)
-            all_rows, all_ids = gather_matches(*pack_results(results, rank, world, B))
+            all_rows, all_ids = gather_matches(*pack_results(results, rank, world, B, device=dev))
             nrows = all_rows.shape[0]
             assert all_ids.dtype == torch.int64 and all_ids.shape[0] == nrows
         barrier()
@@ -267,38 +479,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
-    def roofline_of(mode, events):
-        M = MODES[mode]
-        kern_ms = [a.elapsed_time(b) for a, b, _, _ in events]
-        flop = sum(n * lv * FLOP_PER_PROPOSAL_LEVEL for _, _, n, lv in events) / max(len(events), 1)
-        avg_ms = sum(kern_ms) / max(len(kern_ms), 1)
-        # achieved = ALGORITHMIC flop of one regress launch (608.3 MFLOP per proposal and level) / its
-        # average duration (HIP events on the launch stream)
-        achieved = flop / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        r = {"kernel": M["kernel"], "bound": "mfma", "achieved": achieved, "peak": M["peak"], "unit": "TFLOP/s",
-             "frac": achieved / M["peak"], "traffic": None, "avg_launch_ms": avg_ms, "algorithmic_flop_per_launch": flop,
-             "peak_note": M["peak_note"],
-             "note": "achieved = algorithmic flop of the launch (608.3 MFLOP x proposals x levels) / launch time "
-                     "measured with HIP events on the launch stream"}
-        return r
-
     value = world * args.steps * B / elapsed
     if rank == 0:
         roof = roofline_of(mode, events)
-        # HBM traffic of the dominant kernel: PMC measurement (tools/collect_profiles.sh) of THIS source tree, same
-        # kernel and launch size -- otherwise null
-        tf = os.path.join(ROOT, "profiles", "regress_traffic.json")
-        if os.path.exists(tf):
-            rec = json.load(open(tf)).get(mode, {})
-            if (rec.get("kernel") == MODES[mode]["kernel"] and rec.get("proposals_per_launch") == B * PTMAX * cfg["panc"]
-                    and rec.get("config", "A") == args.config and rec.get("source_hash") == source_hash()):
-                roof["traffic"] = rec.get("hbm_bytes_per_launch")
-                roof["traffic_source"] = rec.get("source")
-                roof["traffic_note"] = ("FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE of the kernel per launch = requests on the "
-                                        "L2's fabric side: Infinity-Cache hits are included, so this is an upper bound of the HBM "
-                                        "bytes; the compulsory bytes of the launch are ~1 GB (16 x 61 MB of pyramids + 57 MB of "
-                                        "weights), the rest are L2 capacity misses of the 28.5 MB-per-level weight stream, which "
-                                        "lives in the 256 MB Infinity Cache")
+        add_traffic(roof, mode, args.config, B * PTMAX * cfg["panc"])
         # the path's compulsory HBM bytes per pair against the 8 TB/s roofline, as north_star asks
         alg_bytes = 118e6 if args.config == "A" else 0.42e9
         out = {
@@ -313,11 +497,13 @@ def main():
                              "peak_GBps": 8000.0, "frac": value / world * alg_bytes / 8e12,
                              "note": "compulsory bytes of the whole path per pair (SURVEY 8d) x pairs/s per GPU; the path "
                                      "is MFMA-bound (4300 flop/B), so this fraction is << 1 by construction"},
+            "per_gpu_pairs_per_s": value / world,
         }
     # ---- outside the timed region (single-GPU runs only) ----
     if rank == 0 and world == 1:
+        out["coarse_stage_ms_per_pair"] = coarse_stage_ms(net, batches[0])
         if not args.no_parity:
-            out["parity"] = parity_check(net, ckpt, batches[0], cpu_pairs[0], cfg)
+            out["parity"] = parity_check(net, ckpt, batches[0], cpu_pairs, cfg)
         if not args.no_other_modes:
             other = {}
             for m2 in MODES:
@@ -334,11 +520,16 @@ def main():
                              "roofline_frac": r2["frac"], "achieved": r2["achieved"], "peak": r2["peak"],
                              "avg_launch_ms": r2["avg_launch_ms"]}
                 if not args.no_parity:
-                    p2 = parity_check(net, ckpt, batches[0], cpu_pairs[0], cfg)
+                    p2 = parity_check(net, ckpt, batches[0], cpu_pairs, cfg, pairs=1)
                     other[m2].update({k: p2.get(k) for k in ("max_px_err_mid", "max_px_err", "max_score_err")})
             for w in net._weights()[1:]:
                 w.set_mode(mode)
             out["other_modes"] = other
+        if not args.no_other_configs and args.config == "A":
+            try:
+                out["other_configs"] = {"E": config_leg(net, "E", mode, rank, dev)}
+            except Exception as e:       # informational leg; never fail the bench line on it
+                out["other_configs"] = {"E": {"error": repr(e)}}
         if not args.no_e2e and args.config == "A":
             try:
                 from tools import e2e_bench

@@ -138,9 +138,14 @@ int p2p_coarse_matches_batch(const float *corr4d, const uint8_t *delta, int batc
  * the list as it was; then rows with score > ncn_thres, again "or everything".
  *   matches [B,n,4] int64, scores [B,n] fp32  ->  out_matches [B,n,4], out_scores [B,n] (first out_counts[b] rows
  *   valid), out_counts [B] int32 on the device; out_counts[b] = -1 if a coordinate is negative or >= 2^15 (the caller
- *   falls back to the host path).  n <= 8192 rows per item (P2P_EUNSUPPORTED beyond).                            */
+ *   falls back to the host path).
+ * Lists of up to 8192 rows are filtered entirely in LDS and need no workspace (NULL, 0).  Longer lists (a 960x1280 pair
+ * at ksize 2 has 9600 rows) are sorted in `workspace`, p2p_filter_coarse_workspace_bytes(batch, n) bytes of device
+ * memory (0 for n <= 8192; P2P_ENOMEM if it is missing or too small); n <= 2^20.                                  */
+size_t p2p_filter_coarse_workspace_bytes(int batch, int n);
 int p2p_filter_coarse_batch(const int64_t *matches, const float *scores, int batch, int n, float ncn_thres, int mutual,
-                            int64_t *out_matches, float *out_scores, int *out_counts, p2p_stream_t stream);
+                            int64_t *out_matches, float *out_scores, int *out_counts, void *workspace,
+                            size_t workspace_bytes, p2p_stream_t stream);
 
 /* The tail of estimate_matches -- reference utils/eval/model_helper.py:92-109 -- for a batch with device-side counts:
  * per item keep the rows with fine score > io_thres (all rows if none passes), in order, and scale refined and coarse

@@ -31,9 +31,16 @@ class _AliasLoader(importlib.abc.Loader):
 
 
 class _AliasFinder(importlib.abc.MetaPathFinder):
+    """Answers only for SUBMODULES of `networks` / `utils`, and only while the bare top-level name is bound to this
+    package's module: the top-level names themselves are found by the ordinary path finder (whose __init__.py calls
+    `bootstrap`), so another project's `utils` package is importable again as soon as sys.modules['utils'] is not ours
+    (e.g. after `uninstall()` or `del sys.modules['utils']`)."""
+
     def find_spec(self, fullname, path=None, target=None):
-        head = fullname.partition(".")[0]
-        if head not in _ROOTS:
+        head, _, rest = fullname.partition(".")
+        if head not in _ROOTS or not rest:
+            return None
+        if getattr(sys.modules.get(head), "__name__", None) != "patch2pix_amd." + head:
             return None
         try:
             real = importlib.import_module("patch2pix_amd." + fullname)
@@ -48,6 +55,14 @@ class _AliasFinder(importlib.abc.MetaPathFinder):
 def install():
     if not any(isinstance(f, _AliasFinder) for f in sys.meta_path):
         sys.meta_path.insert(0, _AliasFinder())
+
+
+def uninstall():
+    """Remove the finder and every bare alias from sys.modules (the patch2pix_amd.* modules stay loaded)."""
+    sys.meta_path[:] = [f for f in sys.meta_path if not isinstance(f, _AliasFinder)]
+    for name in list(sys.modules):
+        if name.partition(".")[0] in _ROOTS and getattr(sys.modules[name], "__name__", "").startswith("patch2pix_amd."):
+            del sys.modules[name]
 
 
 def bootstrap(bare_name, init_file):

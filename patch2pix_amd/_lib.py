@@ -69,9 +69,10 @@ p2p_coarse_matches = _sig("p2p_coarse_matches", ctypes.c_int,
 p2p_coarse_matches_batch = _sig("p2p_coarse_matches_batch", ctypes.c_int,
                                 [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 8 +
                                 [ctypes.c_void_p, ctypes.c_void_p, c_stream])
+p2p_filter_coarse_workspace_bytes = _sig("p2p_filter_coarse_workspace_bytes", ctypes.c_size_t, [ctypes.c_int, ctypes.c_int])
 p2p_filter_coarse_batch = _sig("p2p_filter_coarse_batch", ctypes.c_int,
                                [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int,
-                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_stream])
+                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, c_stream])
 p2p_match_tail_batch = _sig("p2p_match_tail_batch", ctypes.c_int,
                             [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_float] + [ctypes.c_void_p] * 4 + [c_stream])
 p2p_regress = _sig("p2p_regress", ctypes.c_int,
@@ -92,7 +93,7 @@ REGRESS_MODES = {"f32": 0, "bf16x2": 1, "bf16x3": 2}
 
 EXPORTS = ["p2p_version", "p2p_last_error", "p2p_ncn_create", "p2p_ncn_destroy", "p2p_regressor_create",
            "p2p_regressor_destroy", "p2p_coarse_workspace_bytes", "p2p_coarse_forward", "p2p_coarse_forward_batch",
-           "p2p_delta_unpack", "p2p_coarse_matches", "p2p_coarse_matches_batch", "p2p_filter_coarse_batch", "p2p_match_tail_batch", "p2p_regress", "p2p_regress_batch", "p2p_regress_batch_dev", "p2p_regressor_set_mode",
+           "p2p_delta_unpack", "p2p_coarse_matches", "p2p_coarse_matches_batch", "p2p_filter_coarse_workspace_bytes", "p2p_filter_coarse_batch", "p2p_match_tail_batch", "p2p_regress", "p2p_regress_batch", "p2p_regress_batch_dev", "p2p_regressor_set_mode",
            "p2p_regressor_get_mode"]
 
 

@@ -11,5 +11,5 @@ void set_error(const char *fmt, ...) {
 }
 }  // namespace p2p
 
-extern "C" int p2p_version(void) { return 100; }
+extern "C" int p2p_version(void) { return 101; }
 extern "C" const char *p2p_last_error(void) { return p2p::g_err; }

@@ -2,14 +2,18 @@
 // the host's numpy RNG and stays on the host): per batch item, the lexicographically sorted distinct rows of the
 // [n,4] int64 match list with the score of their first occurrence; `mutual` keeps rows that occur more than once;
 // if nothing is kept the list stays as it was; then rows with score > ncn_thres, again "or everything".
-// One work-group per item: packed 64-bit keys (4 x 16 bits, pixel coordinates are < 2^15) + original index in LDS,
-// bitonic sort, run detection, two order-preserving compactions.
+// One work-group per item: packed 64-bit keys (4 x 16 bits, pixel coordinates are < 2^15) + original index,
+// bitonic sort, run detection, two order-preserving compactions.  Up to 8192 rows (padded to a power of two) the whole
+// item lives in LDS.  Longer lists (a 960x1280 pair has 9600 rows, a 1600-pixel image 15000) are sorted in a
+// caller-provided workspace: chunks of 8192 rows are sorted in LDS, the network steps whose stride spans chunks run on
+// global memory (the work-group's own stores, ordered by its barriers), the rest of every merge again chunk-wise in LDS.
 #include "p2p_common.h"
 
 namespace p2p {
 
 constexpr int FT = 1024;                      // threads per work-group
-constexpr int FILTER_MAX_ROWS = 8192;         // (8 + 4 + 4) bytes of LDS per padded row
+constexpr int FILTER_LDS_ROWS = 8192;         // rows held in LDS at a time
+constexpr int FILTER_MAX_ROWS = 1 << 20;      // workspace path: 16 bytes of workspace per padded row
 
 struct FilterArgs {
     const long long *matches;                 // [B][n][4]
@@ -20,6 +24,7 @@ struct FilterArgs {
     long long *out_matches;                   // [B][n][4]
     float *out_scores;                        // [B][n]
     int *out_counts;                          // [B]; -1 = a coordinate did not fit the packed key (caller falls back)
+    unsigned char *ws;                        // BIG only: npad * 16 bytes per item (keys, indices, kept-row list)
 };
 
 // exclusive prefix sum of one int per thread over the work-group; returns the total through *total
@@ -49,14 +54,45 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *wave_sums, int *
     return base + incl - v;
 }
 
+// one compare-exchange of the bitonic network on (key, original index): equal rows stay in input order, so a run of
+// equal keys starts with its first occurrence
+__device__ __forceinline__ void cmp_xchg(unsigned long long *key, int *idx, int lo, int hi, bool up) {
+    const unsigned long long kl = key[lo], kh = key[hi];
+    const int il = idx[lo], ih = idx[hi];
+    const bool greater = kl > kh || (kl == kh && il > ih);
+    if (greater == up) { key[lo] = kh; key[hi] = kl; idx[lo] = ih; idx[hi] = il; }
+}
+
+// the steps stride_first, stride_first / 2, ..., 1 of the merge of width `size` on `count` rows that start at global
+// position `base` of the item (the direction of a pair depends on its global position)
+__device__ __forceinline__ void bitonic_steps(unsigned long long *key, int *idx, int count, int base, int size, int stride_first) {
+    for (int stride = stride_first; stride > 0; stride >>= 1) {
+        for (int t = threadIdx.x; t < count / 2; t += FT) {
+            const int lo = 2 * t - (t & (stride - 1));
+            cmp_xchg(key, idx, lo, lo + stride, ((base + lo) & size) == 0);
+        }
+        __syncthreads();
+    }
+}
+
+template <bool BIG>
 __global__ __launch_bounds__(FT) void filter_coarse_kernel(FilterArgs a) {
     P2P_DYN_SHARED(unsigned char, fsm);
-    unsigned long long *key = (unsigned long long *)fsm;              // [npad]
-    int *idx = (int *)(fsm + (size_t)a.npad * 8);                      // [npad]  original row of a sorted position
-    int *pos = idx + a.npad;                                           // [npad]  scratch: list of kept source rows
+    constexpr int CH = FILTER_LDS_ROWS;
+    const int lrows = BIG ? CH : a.npad;                                // rows in LDS
+    unsigned long long *lkey = (unsigned long long *)fsm;              // [lrows]
+    int *lidx = (int *)(fsm + (size_t)lrows * 8);                      // [lrows]  original row of a sorted position
     __shared__ int wave_sums[FT / 64];
     __shared__ int flag_bad;
     const int tid = threadIdx.x, item = blockIdx.x;
+    unsigned long long *key = lkey;
+    int *idx = lidx, *pos = lidx + a.npad;                             // pos [npad]: list of kept source rows
+    if (BIG) {
+        unsigned char *w = a.ws + (size_t)item * a.npad * 16;
+        key = (unsigned long long *)w;
+        idx = (int *)(w + (size_t)a.npad * 8);
+        pos = idx + a.npad;
+    }
     const long long *rows = a.matches + (size_t)item * a.n * 4;
     const float *sc = a.scores + (size_t)item * a.n;
     long long *orow = a.out_matches + (size_t)item * a.n * 4;
@@ -79,19 +115,37 @@ __global__ __launch_bounds__(FT) void filter_coarse_kernel(FilterArgs a) {
         if (tid == 0) a.out_counts[item] = -1;
         return;
     }
-    // bitonic sort by (key, original index): equal rows stay in input order, so a run starts with its first occurrence
-    for (int size = 2; size <= a.npad; size <<= 1)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = tid; t < a.npad / 2; t += FT) {
-                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const unsigned long long kl = key[lo], kh = key[hi];
-                const int il = idx[lo], ih = idx[hi];
-                const bool greater = kl > kh || (kl == kh && il > ih);
-                if (greater == up) { key[lo] = kh; key[hi] = kl; idx[lo] = ih; idx[hi] = il; }
-            }
+    if (!BIG) {
+        for (int size = 2; size <= a.npad; size <<= 1) bitonic_steps(key, idx, a.npad, 0, size, size >> 1);
+    } else {
+        auto load = [&](int c0) {
+            for (int i = tid; i < CH; i += FT) { lkey[i] = key[c0 + i]; lidx[i] = idx[c0 + i]; }
             __syncthreads();
+        };
+        auto store = [&](int c0) {
+            for (int i = tid; i < CH; i += FT) { key[c0 + i] = lkey[i]; idx[c0 + i] = lidx[i]; }
+            __syncthreads();
+        };
+        for (int c0 = 0; c0 < a.npad; c0 += CH) {
+            load(c0);
+            for (int size = 2; size <= CH; size <<= 1) bitonic_steps(lkey, lidx, CH, c0, size, size >> 1);
+            store(c0);
         }
+        for (int size = 2 * CH; size <= a.npad; size <<= 1) {
+            for (int stride = size >> 1; stride >= CH; stride >>= 1) {
+                for (int t = tid; t < a.npad / 2; t += FT) {
+                    const int lo = 2 * t - (t & (stride - 1));
+                    cmp_xchg(key, idx, lo, lo + stride, (lo & size) == 0);
+                }
+                __syncthreads();
+            }
+            for (int c0 = 0; c0 < a.npad; c0 += CH) {
+                load(c0);
+                bitonic_steps(lkey, lidx, CH, c0, size, CH >> 1);
+                store(c0);
+            }
+        }
+    }
     // stage 1: run starts (first occurrences in sorted order), with `mutual` only runs longer than one
     const int per = (a.n + FT - 1) / FT, i0 = min(tid * per, a.n), i1 = min(i0 + per, a.n);
     int mine = 0;
@@ -206,25 +260,41 @@ extern "C" int p2p_match_tail_batch(const float *fine, const float *scores, cons
     return check_launch("match_tail_kernel");
 }
 
+extern "C" size_t p2p_filter_coarse_workspace_bytes(int batch, int n) {
+    if (batch < 1 || n < 1 || n > FILTER_MAX_ROWS) return 0;
+    if (n <= FILTER_LDS_ROWS) return 0;
+    size_t npad = 2;
+    while (npad < (size_t)n) npad <<= 1;
+    return (size_t)batch * npad * 16;
+}
+
 extern "C" int p2p_filter_coarse_batch(const int64_t *matches, const float *scores, int batch, int n, float ncn_thres,
                                        int mutual, int64_t *out_matches, float *out_scores, int *out_counts,
-                                       p2p_stream_t stream) {
+                                       void *workspace, size_t workspace_bytes, p2p_stream_t stream) {
     P2P_REQUIRE(matches && scores && out_matches && out_scores && out_counts, P2P_EINVAL, "p2p_filter_coarse: null argument");
     P2P_REQUIRE(batch >= 1 && batch <= 65535 && n >= 1, P2P_EINVAL, "p2p_filter_coarse: bad sizes");
-    P2P_REQUIRE(n <= FILTER_MAX_ROWS, P2P_EUNSUPPORTED, "p2p_filter_coarse: %d rows per item (device path holds %d)", n,
-                FILTER_MAX_ROWS);
+    P2P_REQUIRE(n <= FILTER_MAX_ROWS, P2P_EUNSUPPORTED, "p2p_filter_coarse: %d rows per item (at most %d)", n, FILTER_MAX_ROWS);
     int npad = 2;
     while (npad < n) npad <<= 1;
-    const size_t lds = (size_t)npad * 16;
+    const bool big = n > FILTER_LDS_ROWS;
+    const size_t need = p2p_filter_coarse_workspace_bytes(batch, n);
+    P2P_REQUIRE(!big || (workspace && workspace_bytes >= need), P2P_ENOMEM,
+                "p2p_filter_coarse: %d rows per item need a workspace of %zu bytes (p2p_filter_coarse_workspace_bytes), got %zu",
+                n, need, workspace ? workspace_bytes : (size_t)0);
+    const size_t lds = big ? (size_t)FILTER_LDS_ROWS * 12 : (size_t)npad * 16;
     int dev = 0;
     P2P_HIP_CHECK(hipGetDevice(&dev));
     static bool attr_set[64] = {false};      // per device: a process may drive several GPUs
-    if (dev < 64 && !attr_set[dev]) {
-        P2P_HIP_CHECK(hipFuncSetAttribute((const void *)filter_coarse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          FILTER_MAX_ROWS * 16));
-        attr_set[dev] = true;
+    if (dev >= 64 || !attr_set[dev]) {
+        P2P_HIP_CHECK(hipFuncSetAttribute((const void *)filter_coarse_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          FILTER_LDS_ROWS * 16));
+        P2P_HIP_CHECK(hipFuncSetAttribute((const void *)filter_coarse_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          FILTER_LDS_ROWS * 12));
+        if (dev < 64) attr_set[dev] = true;
     }
-    FilterArgs a{(const long long *)matches, scores, n, npad, ncn_thres, mutual, (long long *)out_matches, out_scores, out_counts};
-    hipLaunchKernelGGL(filter_coarse_kernel, dim3(batch), dim3(FT), lds, (hipStream_t)stream, a);
+    FilterArgs a{(const long long *)matches, scores, n, npad, ncn_thres, mutual, (long long *)out_matches, out_scores, out_counts,
+                 (unsigned char *)workspace};
+    if (big) hipLaunchKernelGGL(filter_coarse_kernel<true>, dim3(batch), dim3(FT), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(filter_coarse_kernel<false>, dim3(batch), dim3(FT), lds, (hipStream_t)stream, a);
     return check_launch("filter_coarse_kernel");
 }

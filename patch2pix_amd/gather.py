@@ -11,11 +11,13 @@ def shard_pairs(num_pairs, rank, world):
     return list(range(rank, num_pairs, world))
 
 
-def pack_results(results, rank, world, pairs_per_step):
+def pack_results(results, rank, world, pairs_per_step, device=None, dtype=torch.float32):
     """What a rank contributes to the final gather: `results` = its steps, each a (fine, score, coarse) triple of
     per-pair lists ([n,4] fp32, [n] fp32, [n,4] int64).  Returns (rows [M,9] fp32 = fine, score, coarse; ids [M] int64);
     the global id of pair b of step i of rank r is (i * world + r) * pairs_per_step + b, i.e. steps are dealt
-    round-robin over the ranks like `shard_pairs` deals pairs."""
+    round-robin over the ranks like `shard_pairs` deals pairs.  `device` / `dtype`: where and as what an EMPTY contribution
+    is created (a rank without results must still enter the collective with tensors on its GPU: under RCCL a CPU tensor
+    on one rank against GPU tensors on the others errors or hangs)."""
     rows, ids = [], []
     for i, (fine, score, coarse) in enumerate(results):
         for b in range(pairs_per_step):
@@ -23,7 +25,7 @@ def pack_results(results, rank, world, pairs_per_step):
             ids.append(torch.full((fine[b].shape[0],), (i * world + rank) * pairs_per_step + b, dtype=torch.int64,
                                   device=fine[b].device))
     if not rows:
-        return torch.zeros((0, 9)), torch.zeros((0,), dtype=torch.int64)
+        return torch.zeros((0, 9), dtype=dtype, device=device), torch.zeros((0,), dtype=torch.int64, device=device)
     return torch.cat(rows), torch.cat(ids)
 
 
@@ -56,3 +58,51 @@ def gather_matches(rows, pair_ids, group=None):
     dist.all_gather(gathered_ids, ids, group=group)
     return (torch.cat([g[:n] for g, n in zip(gathered, counts)]),
             torch.cat([g[:n] for g, n in zip(gathered_ids, counts)]))
+
+
+def stream_rounds(num_pairs, world, chunk, gather_every):
+    """Number of exchange rounds of `run_pair_stream` -- a function of the global sizes only, so every rank enters the
+    same number of collectives whatever its own share is."""
+    per_rank = -(-num_pairs // world)
+    return max(1, -(-(-(-per_rank // chunk)) // gather_every))
+
+
+def run_pair_stream(num_pairs, rank, world, chunk, submit, finish, gather_every=8, device=None, group=None, on_chunk=None,
+                    exchange=True):
+    """BASELINE configs[3]: a stream of `num_pairs` independent pairs, pair `i` handled by rank `i % world`
+    (`shard_pairs`), `chunk` pairs per submission, results exchanged every `gather_every` chunks with `gather_matches`
+    (the only collective of the path).  Software-pipelined one chunk ahead: `submit(pair_ids) -> ticket` enqueues a
+    chunk, `finish(ticket) -> (fine, score, coarse)` (per-pair lists) completes it, so the device never waits for the
+    host between chunks.  Returns (rows [M,9], pair_ids [M]) of ALL ranks on every rank, concatenated over the rounds,
+    and the number of pairs this rank processed.  exchange=False keeps the results local (no collective: a rank running
+    on its own while a process group exists)."""
+    mine = shard_pairs(num_pairs, rank, world)
+    chunks = [mine[i:i + chunk] for i in range(0, len(mine), chunk)]
+    rounds = stream_rounds(num_pairs, world, chunk, gather_every)
+    out_rows, out_ids, done = [], [], 0
+    ticket = submit(chunks[0]) if chunks else None
+    nxt = 1
+    for r in range(rounds):
+        rows, ids = [], []
+        for _ in range(gather_every):
+            if ticket is None:
+                break
+            cur_ids = chunks[nxt - 1]
+            following = submit(chunks[nxt]) if nxt < len(chunks) else None
+            fine, score, coarse = finish(ticket)
+            for j, pid in enumerate(cur_ids):
+                rows.append(torch.cat([fine[j], score[j][:, None], coarse[j].to(fine[j].dtype)], dim=1))
+                ids.append(torch.full((fine[j].shape[0],), pid, dtype=torch.int64, device=fine[j].device))
+            done += len(cur_ids)
+            if on_chunk is not None:
+                on_chunk(cur_ids)
+            ticket, nxt = following, nxt + 1
+        if rows:
+            packed = (torch.cat(rows), torch.cat(ids))
+        else:
+            packed = (torch.zeros((0, 9), device=device), torch.zeros((0,), dtype=torch.int64, device=device))
+        g_rows, g_ids = gather_matches(*packed, group=group) if exchange else packed
+        out_rows.append(g_rows)
+        out_ids.append(g_ids)
+    assert ticket is None, "stream_rounds under-counted the rounds"
+    return torch.cat(out_rows), torch.cat(out_ids), done

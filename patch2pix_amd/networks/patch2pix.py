@@ -313,7 +313,8 @@ class Patch2Pix(nn.Module):
         regressors reading the proposal counts from device memory.  Returns padded device tensors
         (fine [B,n,4], fine_scores [B,n], coarse [B,n,4] int64, counts int32 [B]); `unpad` turns them into the lists
         predict_fine returns.  Not available for the training-time options (ptmax, panc > 1) and for images whose pixel
-        coordinates do not fit 15 bits -- use predict_fine_from_feats there."""
+        coordinates do not fit 15 bits -- use predict_fine_from_feats there.  Any number of coarse rows up to 2^20 per
+        pair (lists beyond the 8192 rows that fit LDS are sorted through a scratch buffer, csrc/filter.hip)."""
         if self.panc != 1:
             raise NotImplementedError("predict_fine_device: panc > 1 goes through predict_fine_from_feats")
         if max(feats1[0].shape[-2:] + feats2[0].shape[-2:]) >= (1 << 15):
@@ -329,8 +330,13 @@ class Patch2Pix(nn.Module):
 
     @staticmethod
     def unpad(fine, fine_scores, coarse, counts):
-        """One device-to-host copy of the counts, then per-item views: the (fine, scores, coarse) lists of predict_fine."""
+        """One device-to-host copy of the counts, then per-item views: the (fine, scores, coarse) lists of predict_fine.
+        A count of -1 (the device filter met a coordinate outside its packed key) raises: the padded rows of that item
+        hold nothing, use predict_fine_from_feats for such inputs."""
         n = counts.cpu().tolist()
+        if any(c < 0 for c in n):
+            raise RuntimeError("Patch2Pix.unpad: the device-side filter_coarse asked for the host path (count -1: a "
+                               "coordinate outside [0, 2^15)); call predict_fine_from_feats / estimate_matches instead")
         return ([fine[b, :c] for b, c in enumerate(n)], [fine_scores[b, :c] for b, c in enumerate(n)],
                 [coarse[b, :c] for b, c in enumerate(n)])
 

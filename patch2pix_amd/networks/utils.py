@@ -63,7 +63,7 @@ def filter_coarse(coarse_matches, match_scores, ncn_thres=0.0, mutual=True, ptma
     if device.type == "cuda":
         # through recycled pinned buffers: a copy from pageable memory would block the host until the stream
         # has drained, i.e. idle the GPU while the next launch is being prepared
-        pin_r, pin_s, done = _pinned(rows_np.shape[0])
+        pin_r, pin_s, done = _pinned(rows_np.shape[0], device)
         pin_r[:rows_np.shape[0]].copy_(torch.from_numpy(rows_np))
         pin_s[:rows_np.shape[0]].copy_(torch.from_numpy(scores_np))
         all_rows = pin_r[:rows_np.shape[0]].to(device, non_blocking=True)
@@ -74,25 +74,24 @@ def filter_coarse(coarse_matches, match_scores, ncn_thres=0.0, mutual=True, ptma
     return list(torch.split(all_rows, counts)), list(torch.split(all_scores, counts))
 
 
-_pin_ring, _pin_turn = [], [0]
+_pin_rings = {}      # device index -> [ring of 8 slots, turn]
 
 
-def _pinned(n):
-    """(rows int64 [cap,4], scores f32 [cap], event) -- pinned staging buffers from a ring of 8.  The event is recorded
+def _pinned(n, device):
+    """(rows int64 [cap,4], scores f32 [cap], event) -- pinned staging buffers from a ring of 8 PER DEVICE (an event
+    belongs to the device of the stream it was recorded on; one process may drive several GPUs).  The event is recorded
     by the caller after its asynchronous upload; a slot is handed out again only after that upload has completed, so a
     host that runs more than 8 uploads ahead of the stream waits here instead of overwriting a buffer still being read."""
-    if len(_pin_ring) < 8:
-        _pin_ring.append(None)
-    slot = _pin_turn[0] % 8
-    _pin_turn[0] += 1
-    if slot >= len(_pin_ring):
-        _pin_ring.extend([None] * (slot + 1 - len(_pin_ring)))
-    buf = _pin_ring[slot]
+    ring = _pin_rings.setdefault(device.index if device.index is not None else torch.cuda.current_device(), [[None] * 8, 0])
+    slot = ring[1] % 8
+    ring[1] += 1
+    buf = ring[0][slot]
     if buf is not None:
         buf[2].synchronize()
     if buf is None or buf[0].shape[0] < n:
         cap = max(1024, 1 << (max(n, 1) - 1).bit_length())
-        buf = (torch.empty((cap, 4), dtype=torch.int64).pin_memory(), torch.empty((cap,), dtype=torch.float32).pin_memory(),
-               torch.cuda.Event())
-        _pin_ring[slot] = buf
+        with torch.cuda.device(device):
+            buf = (torch.empty((cap, 4), dtype=torch.int64).pin_memory(), torch.empty((cap,), dtype=torch.float32).pin_memory(),
+                   torch.cuda.Event())
+        ring[0][slot] = buf
     return buf

@@ -197,7 +197,8 @@ def coarse_matches(corr, delta, ksize, upsample, center=True, out_matches=None, 
 def filter_coarse_batch(matches, scores, ncn_thres=0.0, mutual=True):
     """filter_coarse (networks/utils.py:38-72, no ptmax) on the device for a batch: matches [B,n,4] int64, scores [B,n]
     fp32 -> (rows [B,n,4], scores [B,n], counts int32 [B]); the first counts[b] rows of item b are valid, in the
-    reference's order.  counts[b] == -1 asks for the host path (a coordinate outside [0, 2^15))."""
+    reference's order.  counts[b] == -1 asks for the host path (a coordinate outside [0, 2^15)).  Any n up to 2^20:
+    lists longer than 8192 rows are sorted through a scratch buffer (16 bytes per padded row)."""
     if matches.dtype != torch.int64 or matches.dim() != 3 or matches.shape[-1] != 4 or not matches.is_cuda:
         raise TypeError("matches must be an int64 [B,n,4] tensor on the GPU")
     scores = _f32c(scores, "scores")
@@ -208,9 +209,12 @@ def filter_coarse_batch(matches, scores, ncn_thres=0.0, mutual=True):
     counts = torch.empty((nb,), dtype=torch.int32, device=dev)
     if nb and n:
         with torch.cuda.device(dev):
+            need = _lib.p2p_filter_coarse_workspace_bytes(nb, n)
+            ws = torch.empty(need, dtype=torch.uint8, device=dev) if need else None      # stream-ordered by the allocator
             _lib.check(_lib.p2p_filter_coarse_batch(matches.data_ptr(), scores.data_ptr(), nb, n, float(ncn_thres),
                                                     int(bool(mutual)), out_m.data_ptr(), out_s.data_ptr(),
-                                                    counts.data_ptr(), _stream()), "p2p_filter_coarse_batch")
+                                                    counts.data_ptr(), ws.data_ptr() if need else None, need, _stream()),
+                       "p2p_filter_coarse_batch")
     else:
         counts.zero_()
     return out_m, out_s, counts

@@ -206,6 +206,27 @@ def make_correlated_pyramids(seed, height, width, shift=(8, 16), noise=0.25, dev
     return [t.to(device) for t in p1], p2
 
 
+def make_correlated_pyramids_device(pair_id, height, width, device, shift=(8, 16), noise=0.25):
+    """The same construction as `make_correlated_pyramids`, generated ON the device from a generator seeded with the
+    pair id (another random stream than the CPU version: used where no CPU counterpart of the inputs is needed -- the
+    pair stream of bench.py --pairs N, whose 10 000 pairs cannot all be resident)."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(pair_id))
+    dims = ((3, 1, False), (64, 2, True), (64, 4, True), (128, 8, True), (256, 8, True))
+    p1, p2 = [], []
+    for c, ds, relu in dims:
+        t = torch.randn(c, height // ds, width // ds, generator=gen, device=device)
+        if relu:
+            t = torch.relu(t + 0.3)
+        r = torch.roll(t, shifts=(shift[0] // ds, shift[1] // ds), dims=(1, 2))
+        r = r + noise * torch.randn(r.shape, generator=gen, device=device)
+        if ds > 1:
+            r = torch.relu(r)
+        p1.append(t)
+        p2.append(r)
+    return p1, p2
+
+
 def make_image_pair(seed, height=480, width=640, shift=(16, 24)):
     """Two uint8 RGB images [H,W,3]: a multi-scale random texture and a shifted, re-noised copy."""
     import numpy as np

@@ -122,8 +122,12 @@ def filter_coarse_batch(emu, matches, scores, thres, mutual):
     nb, n, _ = matches.shape
     om, osc = torch.empty_like(matches), torch.empty_like(scores)
     cnt = torch.empty(nb, dtype=torch.int32)
-    check(emu, emu.p2p_filter_coarse_batch(ptr(matches), ptr(scores), nb, n, float(thres), int(mutual), ptr(om), ptr(osc),
-                                           ptr(cnt), None), "p2p_filter_coarse_batch")
+    emu.p2p_filter_coarse_workspace_bytes.restype = ctypes.c_size_t
+    need = emu.p2p_filter_coarse_workspace_bytes(nb, n)
+    ws = torch.empty(max(need, 1), dtype=torch.uint8)
+    check(emu, emu.p2p_filter_coarse_batch(ptr(matches), ptr(scores), nb, n, ctypes.c_float(thres), int(mutual), ptr(om), ptr(osc),
+                                           ptr(cnt), ptr(ws) if need else None, ctypes.c_size_t(need), None),
+          "p2p_filter_coarse_batch")
     out = []
     for b in range(nb):
         c = int(cnt[b])

@@ -2,6 +2,8 @@
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -99,3 +101,49 @@ def test_bench_final_exchange_on_two_ranks():
                 assert torch.equal(got, want)
                 total += want.shape[0]
     assert rows.shape[0] == total and len(set(ids.tolist())) <= world * steps * B
+
+
+def _stream_worker(rank, world, port, num_pairs, chunk, gather_every, ret):
+    from patch2pix_amd.gather import run_pair_stream
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    log = []
+
+    def submit(pair_ids):                       # stand-in for "generate the chunk's pyramids + coarse_async"
+        log.append(("submit", tuple(pair_ids)))
+        return list(pair_ids)
+
+    def finish(ticket):                         # stand-in matcher: pair id -> (id % 4) rows that encode the id
+        log.append(("finish", tuple(ticket)))
+        n = [pid % 4 for pid in ticket]
+        return ([torch.full((k, 4), float(pid)) for k, pid in zip(n, ticket)], [torch.full((k,), 0.5) for k in n],
+                [torch.full((k, 4), pid, dtype=torch.int64) for k, pid in zip(n, ticket)])
+
+    rows, ids, done = run_pair_stream(num_pairs, rank, world, chunk, submit, finish, gather_every=gather_every)
+    ret[rank] = (rows, ids, done, log)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_pairs,chunk,gather_every", [(37, 4, 2), (5, 4, 3), (1, 2, 2), (64, 8, 8)])
+def test_pair_stream_on_two_ranks(num_pairs, chunk, gather_every):
+    """bench.py --pairs N (BASELINE configs[3]): pair i goes to rank i % world, chunks are pipelined one ahead, results
+    are exchanged every few chunks.  Every pair id must arrive exactly once on every rank, with its own rows, and a rank
+    whose share is empty (1 pair on 2 ranks) still takes part in every collective."""
+    world = 2
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_stream_worker, args=(world, port, num_pairs, chunk, gather_every, ret), nprocs=world, join=True)
+    rows, ids, _, _ = ret[0]
+    assert torch.equal(rows, ret[1][0]) and torch.equal(ids, ret[1][1])
+    assert ret[0][2] + ret[1][2] == num_pairs and ret[0][2] == len(range(0, num_pairs, 2))
+    for pid in range(num_pairs):
+        sel = ids == pid
+        assert int(sel.sum()) == pid % 4
+        assert bool((rows[sel][:, :4] == float(pid)).all()) and bool((rows[sel][:, 5:] == float(pid)).all())
+    assert int(ids.numel()) == sum(p % 4 for p in range(num_pairs))
+    for r in range(world):                      # one chunk ahead: submit(k+1) is issued before finish(k)
+        log = ret[r][3]
+        subs = [i for i, e in enumerate(log) if e[0] == "submit"]
+        fins = [i for i, e in enumerate(log) if e[0] == "finish"]
+        assert len(subs) == len(fins) and all(e[1] == f[1] for e, f in zip([log[i] for i in subs], [log[i] for i in fins]))
+        assert all(subs[k + 1] < fins[k] for k in range(len(fins) - 1))

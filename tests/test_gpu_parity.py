@@ -830,6 +830,19 @@ def test_config_E_vs_oracle(dev, ops, cweights):
     _compare_matches(out["matches1"].cpu(), ref_mid)
     _compare_matches(out["matches2"].cpu(), ref_fine)
     assert (out["probs1"].cpu() - ref_mp).abs().max() <= SCORE_TOL and (out["probs2"].cpu() - ref_fp).abs().max() <= SCORE_TOL
+    # the device path at this size (9600 coarse rows > the 8192 that fit LDS: workspace sort of csrc/filter.hip): device
+    # filter_coarse against the ORACLE's filter on the oracle's rows, regressors on the device-side counts against the oracle
+    net = _model(dev)
+    with torch.no_grad():
+        dfine, dscores, dcoarse, counts = net.predict_fine_device([t[None].to(dev) for t in p1], [t[None].to(dev) for t in p2], ksize=2)
+        fine_l, scores_l, coarse_l = net.unpad(dfine, dscores, dcoarse, counts)
+        ref_sel, _ = orc.filter_coarse(rm, rs, 0.0, True)
+        assert torch.equal(coarse_l[0].cpu(), ref_sel), "device filter_coarse differs from the oracle at 9600 rows"
+        o_mid, _, _ = orc.fine_level(p1[:4], p2[:4], ref_sel, mid_p)
+        o_fine, o_fp, _ = orc.fine_level(p1[:4], p2[:4], o_mid, fine_p)
+    ok = ~_near_integer_rows(o_mid)
+    _compare_matches(fine_l[0].cpu()[ok], o_fine[ok])
+    assert (scores_l[0].cpu()[ok] - o_fp[ok]).abs().max() <= SCORE_TOL and int((~ok).sum()) <= 4
 
 
 def test_documented_import_route_on_gpu(dev, tmp_path):
@@ -857,6 +870,87 @@ print('ROUTE_OK', m.shape, m.dtype, s.dtype, c.shape)
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
     assert res.returncode == 0 and "ROUTE_OK" in res.stdout, res.stderr[-2000:]
     assert "float64 float32" in res.stdout
+
+
+def test_device_filter_against_reference_golden(dev, ops):
+    """p2p_filter_coarse_batch on the 2400 coarse rows the UNMODIFIED REFERENCE produced at 480x640
+    (tests/golden/full_480x640.npz): the mutual set it returns equals the reference's filter_coarse output
+    (networks/utils.py:38-72), rows and order; scores are those of the first occurrences."""
+    g = gu.load("full_480x640")
+    rows = torch.from_numpy(g["all_matches"].astype(np.int64))
+    scores = torch.from_numpy(g["all_scores"])
+    out_m, out_s, counts = ops.filter_coarse_batch(rows[None].to(dev), scores[None].to(dev), 0.0, True)
+    c = int(counts[0])
+    assert np.array_equal(out_m[0, :c].cpu().numpy(), g["mutual_matches"].astype(np.int64))
+    ref_m, ref_s = orc.filter_coarse(rows, scores, 0.0, True)
+    assert torch.equal(out_s[0, :c].cpu(), ref_s) and torch.equal(out_m[0, :c].cpu(), ref_m)
+
+
+def _coarse_like_rows(seed, cells_a, cells_b, mutual_frac=0.3, wmax=1280):
+    """A match list with the structure cal_coarse_matches produces (patch2pix.py:340-375): one row per B cell, then one
+    row per A cell; a fraction of the A->B rows repeats a B->A row (a mutual match)."""
+    g = torch.Generator().manual_seed(seed)
+    n1, n2 = cells_b, cells_a
+    first = torch.randint(0, wmax // 8, (n1, 4), generator=g) * 8 + 4
+    second = torch.randint(0, wmax // 8, (n2, 4), generator=g) * 8 + 4
+    nm = int(mutual_frac * min(n1, n2))
+    second[torch.randperm(n2, generator=g)[:nm]] = first[torch.randperm(n1, generator=g)[:nm]]
+    return torch.cat((first, second)), torch.rand(n1 + n2, generator=g)
+
+
+@pytest.mark.parametrize("cells", [1200, 4800, 7500])      # 2400 rows (480x640), 9600 (960x1280), 15000 (1600-pixel images)
+def test_device_filter_against_oracle(cells, dev, ops):
+    """p2p_filter_coarse_batch against the oracle's filter_coarse (networks/utils.py:38-72) on a batch of three lists:
+    mutual on/off, a threshold some rows pass, a threshold no row passes (second keep-all fall-back, :65-67), a list
+    without any repeated row under `mutual` (first keep-all fall-back, :48-50)."""
+    lists = [_coarse_like_rows(7 * cells + b, cells, cells) for b in range(2)]
+    lists.append(_coarse_like_rows(5, cells, cells, mutual_frac=0.0))
+    rows = torch.stack([l[0] for l in lists]).to(dev)
+    scores = torch.stack([l[1] for l in lists]).to(dev)
+    for mutual, thres in ((True, 0.0), (False, 0.0), (True, 0.6), (False, 0.6), (True, 2.0), (False, 2.0)):
+        out_m, out_s, counts = ops.filter_coarse_batch(rows, scores, thres, mutual)
+        for b in range(3):
+            ref_m, ref_s = orc.filter_coarse(lists[b][0], lists[b][1], thres, mutual)
+            c = int(counts[b])
+            assert c == ref_m.shape[0], (cells, mutual, thres, b, c, ref_m.shape[0])
+            assert torch.equal(out_m[b, :c].cpu(), ref_m) and torch.equal(out_s[b, :c].cpu(), ref_s), (cells, mutual, thres, b)
+
+
+@pytest.mark.parametrize("n", [2400, 9600])
+def test_device_tail_against_reference_semantics(n, dev, ops):
+    """p2p_match_tail_batch against the numpy tail of the reference's estimate_matches (utils/eval/model_helper.py:92-109):
+    rows with fine score > io_thres in order, EVERY row if none passes (:97-105), refined and coarse coordinates scaled
+    to original pixels in float64; a count of -1 passes through."""
+    g = torch.Generator().manual_seed(n)
+    B = 4
+    fine = torch.rand(B, n, 4, generator=g) * 1200
+    scores = torch.rand(B, n, generator=g)
+    scores[2] *= 0.2                                   # item 2: nothing passes 0.25
+    coarse = torch.randint(0, 1280, (B, n, 4), generator=g)
+    counts = torch.tensor([n, n // 3, n - 1, -1], dtype=torch.int32)
+    scale = torch.tensor([[1.0, 1.0, 1.0, 1.0], [1.6, 1.5, 2.0, 2.25], [1.0 / 3.0, 1.7, 1.1, 1.3], [1, 1, 1, 1]], dtype=torch.float64)
+    for io_thres in (0.25, 2.0):
+        om, osc, oc, on = ops.match_tail_batch(fine.to(dev), scores.to(dev), coarse.to(dev), counts.to(dev), scale, io_thres)
+        assert int(on[3]) == -1
+        for b in range(3):
+            c = int(counts[b])
+            f, s, co = fine[b, :c].numpy(), scores[b, :c].numpy(), coarse[b, :c].numpy()
+            pos = np.where(s > io_thres)[0]
+            if len(pos) > 0:
+                f, s, co = f[pos], s[pos], co[pos]
+            up = scale[b].numpy()[None]
+            k = int(on[b])
+            assert k == len(s)
+            assert np.array_equal(om[b, :k].cpu().numpy(), up * f) and np.array_equal(osc[b, :k].cpu().numpy(), s)
+            assert np.array_equal(oc[b, :k].cpu().numpy(), up * co) and om.dtype == torch.float64
+
+
+def test_unpad_refuses_host_fallback_sentinel(dev):
+    """counts == -1 (a coordinate outside the device filter's packed key) must not turn into a slice of garbage."""
+    net = _model(dev)
+    z = torch.zeros(1, 4, 4, device=dev)
+    with pytest.raises(RuntimeError):
+        net.unpad(z, z[..., 0], z.long(), torch.tensor([-1], dtype=torch.int32, device=dev))
 
 
 def test_device_side_filter_path_equals_host_path(dev):

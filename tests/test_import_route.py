@@ -67,3 +67,29 @@ except RuntimeError as e:
 """
     res = _run(code, str(tmp_path))
     assert "LOUD" in res.stdout, res.stdout + res.stderr[-2000:]
+
+
+def test_alias_does_not_capture_foreign_packages(tmp_path):
+    """Another project's top-level `utils` package must stay importable in the same process: the alias finder answers
+    only for submodules of OUR `utils` / `networks`, and `_alias.uninstall()` drops the aliases altogether."""
+    other = tmp_path / "other"
+    (other / "utils").mkdir(parents=True)
+    (other / "utils" / "__init__.py").write_text("WHO = 'foreign'\n")
+    (other / "utils" / "helper.py").write_text("X = 41\n")
+    code = f"""
+import sys
+sys.path.append({PKG!r})
+import utils.eval.model_helper as ours
+assert ours.__name__ == 'patch2pix_amd.utils.eval.model_helper'
+import patch2pix_amd._alias as alias
+alias.uninstall()
+assert 'utils' not in sys.modules and 'utils.eval' not in sys.modules
+sys.path.insert(0, {str(other)!r})
+import utils, utils.helper
+assert utils.WHO == 'foreign' and utils.helper.X == 41
+import patch2pix_amd.utils.eval.model_helper as again
+assert again is ours
+print("FOREIGN_OK")
+"""
+    res = _run(code, str(tmp_path))
+    assert res.returncode == 0 and "FOREIGN_OK" in res.stdout, res.stderr[-3000:]

@@ -261,6 +261,27 @@ def test_device_filter_coarse_against_oracle(seed, emu):
         assert emu_lib.filter_coarse_batch(emu, torch.tensor([[bad, [1, 2, 3, 4]]]), torch.rand(1, 2), 0.0, True) == [None]
 
 
+@pytest.mark.parametrize("n,distinct", [(8192, 5000), (8193, 8000), (9600, 7000), (20000, 3), (40000, 30000)])
+def test_device_filter_coarse_long_lists(n, distinct, emu):
+    """Lists beyond the 8192 rows that fit LDS (a 960x1280 pair has 9600 rows) go through the workspace path: chunks
+    sorted in LDS, chunk-spanning network steps on global memory.  Same contract, same oracle (networks/utils.py:38-72),
+    incl. both keep-all fall-backs."""
+    g = torch.Generator().manual_seed(n)
+    B = 2
+    pool = torch.randint(0, 1281, (B, distinct, 4), generator=g)
+    rows = torch.gather(pool, 1, torch.randint(0, distinct, (B, n), generator=g)[:, :, None].expand(-1, -1, 4))
+    scores = torch.rand(B, n, generator=g)
+    for mutual, thres in ((True, 0.0), (False, 0.5), (True, 2.0)):
+        got = emu_lib.filter_coarse_batch(emu, rows, scores, thres, mutual)
+        for b in range(B):
+            r, rs = orc.filter_coarse(rows[b], scores[b], thres, mutual)
+            assert got[b] is not None and torch.equal(got[b][0], r) and torch.equal(got[b][1], rs)
+    all_distinct = torch.arange(n)[None, :, None].expand(1, n, 4) % 30000                  # mutual selects nothing: keep all
+    got = emu_lib.filter_coarse_batch(emu, all_distinct.contiguous(), scores[:1].contiguous(), 0.0, True)
+    r, rs = orc.filter_coarse(all_distinct[0], scores[0], 0.0, True)
+    assert torch.equal(got[0][0], r) and torch.equal(got[0][1], rs)
+
+
 @pytest.mark.parametrize("mode", ["bf16x3", "bf16x2"])
 def test_regress_with_device_counts(mode, emu, sd):
     """p2p_regress_batch_dev: every item owns `stride` slots, the first counts[i] hold proposals; used slots equal the
