@@ -143,9 +143,14 @@ def parity_check(net, ckpt, batch, cpu_pairs, cfg, pairs=None):
     kernel's own mid matches (a 1e-6 px wobble across an integer would move the whole fine patch by one pixel,
     networks/utils.py:19); `max_px_err_fine_chain` is the plain end-to-end difference (pair 0).  The product samples the
     ptmax proposals pair after pair from the global numpy RNG (networks/utils.py:55-63), the oracle from an equally
-    seeded stream in the same order; where a coarse row differs (an fp32 near-tie, tests/adjudicate.py) the proposals
-    differ legitimately and the fine stage of that pair is compared on the kernel's own proposals."""
+    seeded stream in the same order.  Where a coarse row differs from the fp32 oracle, the pair goes through the fp32
+    error model of oracle/error_model.py: the row must be UNDECIDABLE in fp32 (the two candidates closer in an fp64
+    evaluation than the rounding-error bound of an fp32 one -- the reference's own answer for such a row is an artefact
+    of its summation order) and every decidable row of the pair must hold the fp64 winner; `coarse_indices_equal` is
+    "every row decidable in fp32 is equal".  The proposals of such a pair differ legitimately and its fine stage is
+    compared on the kernel's own proposals."""
     from oracle import p2p_oracle as orc
+    from oracle.error_model import ErrorModel, assert_decidable_rows, differing_rows_are_near_ties
     seed = 4242
     np.random.seed(seed)
     rng = np.random.RandomState(seed)
@@ -159,7 +164,8 @@ def parity_check(net, ckpt, batch, cpu_pairs, cfg, pairs=None):
         torch.cuda.synchronize()
         out = {"pairs_checked": B, "what": f"the first {B} pairs of the benched batch, through the batched calls the bench times",
                "coarse_rows": 0, "coarse_rows_differing": 0, "pairs_with_differing_rows": 0, "proposals": 0,
-               "pairs_with_equal_proposals": 0, "max_px_err_mid": 0.0, "max_px_err": 0.0, "max_score_err": 0.0}
+               "pairs_with_equal_proposals": 0, "max_px_err_mid": 0.0, "max_px_err": 0.0, "max_score_err": 0.0,
+               "coarse_rows_differing_decidable": 0, "worst_gap_over_fp32_error_bound": 0.0}
         for b in range(B):
             p1, p2 = cpu_pairs[b]
             corr, delta = orc.coarse_forward(p1[4], p2[4], KSIZE, ncn)
@@ -171,6 +177,16 @@ def parity_check(net, ckpt, batch, cpu_pairs, cfg, pairs=None):
             out["coarse_rows"] += int(rows.shape[0])
             out["coarse_rows_differing"] += ndiff
             out["pairs_with_differing_rows"] += int(ndiff > 0)
+            if ndiff:
+                try:
+                    em = ErrorModel(p1[4], p2[4], ckpt["state_dict"], KSIZE)
+                    em.check(corr, "oracle fp32 volume")
+                    _, worst = differing_rows_are_near_ties(got_rows, rows, em)
+                    assert_decidable_rows(got_rows, em)
+                    out["worst_gap_over_fp32_error_bound"] = max(out["worst_gap_over_fp32_error_bound"], worst)
+                except AssertionError as e:
+                    out["coarse_rows_differing_decidable"] += ndiff
+                    out.setdefault("errors", []).append(f"pair {b}: {e}")
             out["proposals"] += int(got_props.shape[0])
             same = bool(torch.equal(got_props, cm))
             out["pairs_with_equal_proposals"] += int(same)
@@ -184,7 +200,7 @@ def parity_check(net, ckpt, batch, cpu_pairs, cfg, pairs=None):
             if b == 0:
                 chain, _, _ = orc.fine_level(p1[:4], p2[:4], r_mid, fine_p)
                 out["max_px_err_fine_chain"] = float((fine[0].cpu() - chain).abs().max())
-    out["coarse_indices_equal"] = out["coarse_rows_differing"] == 0
+    out["coarse_indices_equal"] = out["coarse_rows_differing_decidable"] == 0
     out["proposals_equal"] = out["pairs_with_equal_proposals"] == B
     out.update({"tolerance_px": 1e-3, "tolerance_score": 1e-5})
     return out

@@ -13,7 +13,11 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 [ -f $ROOT/profiles/regress_traffic.json ] && cp $ROOT/profiles/regress_traffic.json $OUT/regress_traffic.json
-B="--no-cpu-baseline --no-parity --no-other-modes --no-e2e"
+# P2P_CONFIG=E profiles BASELINE configs[4] (960x1280, 2 pairs x 6400 proposals per step); files are tagged TAG_E_<mode>_*
+CFG=${P2P_CONFIG:-A}
+B="--no-cpu-baseline --no-parity --no-other-modes --no-e2e --no-other-configs --config $CFG"
+[ "$CFG" != "A" ] && TAG=${TAG}_${CFG}
+export P2P_CONFIG=$CFG
 for MODE in $MODES; do
   rm -rf /tmp/prof_k /tmp/prof_p1 /tmp/prof_p2 /tmp/prof_p3
   timeout 240 rocprofv3 --kernel-trace --stats -d /tmp/prof_k -o bench -- python $ROOT/bench.py --mode $MODE --steps 8 --warmup 2 $B > $OUT/${TAG}_${MODE}_profiled_bench.json 2>/dev/null

@@ -17,7 +17,7 @@ def main(out_txt, out_json, mode, dbs):
              "group by kernel_name, counter_name")
         for name, counter, n, val, dur in c.execute(q):
             rows.setdefault(name.split("(")[0], {})[counter] = (n, val, dur)
-    lines = [f"# rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --mode {mode} --steps 3 --warmup 1 (one pass per group)",
+    lines = [f"# rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --config {os.environ.get('P2P_CONFIG', 'A')} --mode {mode} --steps 3 --warmup 1 (one pass per group)",
              "# per-dispatch averages; FETCH_SIZE/WRITE_SIZE in KiB as reported; duration in ns; SQ_* wave counters in quad-cycles",
              "# gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE under-reports wide coalesced reads by 2x -> doubled in the json"]
     for k, v in rows.items():
@@ -33,17 +33,21 @@ def main(out_txt, out_json, mode, dbs):
             act = rg["GRBM_GUI_ACTIVE"]
             clk = act[1] / 8 / (act[2] * 1e-9) / 1e9
             mf = rg["SQ_VALU_MFMA_BUSY_CYCLES"][1] / 1024 / (act[1] / 8) if "SQ_VALU_MFMA_BUSY_CYCLES" in rg else None
-            pairs = int(os.environ.get("P2P_PAIRS_PER_STEP", "16"))      # bench.py default: 16 pairs x 400 proposals
             sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
             import bench
+            config = os.environ.get("P2P_CONFIG", "A")
+            cfg = bench.CONFIGS[config]
+            pairs = int(os.environ.get("P2P_PAIRS_PER_STEP", cfg["pairs_per_step"]))
+            per_pair = cfg["ptmax"] * cfg["panc"]
             allrec = json.load(open(out_json)) if os.path.exists(out_json) else {}
             if "kernel" in allrec:                                        # round-1 format (one un-keyed record)
                 allrec = {}
             lds = None
             if "SQ_LDS_BANK_CONFLICT" in rg and "SQ_LDS_IDX_ACTIVE" in rg and rg["SQ_LDS_IDX_ACTIVE"][1] > 0:
                 lds = rg["SQ_LDS_BANK_CONFLICT"][1] / rg["SQ_LDS_IDX_ACTIVE"][1]
-            allrec[mode] = {"kernel": k.split("::")[-1], "proposals_per_launch": pairs * 400, "config": "A",
-                            "launch": f"{pairs * 400} proposals ({pairs} pairs x 400), 2 levels",
+            allrec[mode if config == "A" else f"{mode}@{config}"] = {
+                            "kernel": k.split("::")[-1], "proposals_per_launch": pairs * per_pair, "config": config,
+                            "launch": f"{pairs * per_pair} proposals ({pairs} pairs x {per_pair}), 2 levels",
                             "hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected_x2": fetch, "write_bytes": write,
                             "effective_clock_ghz": clk, "mfma_busy_fraction": mf, "lds_bank_conflict_fraction": lds,
                             "source_hash": bench.source_hash(), "source": "profiles/" + os.path.basename(out_txt)}
