@@ -57,6 +57,10 @@ MODES = {
                    dtype="f32-equivalent: bf16x3 (every f32 operand = exact sum of 3 bf16 planes, 24 significant bits; "
                          "6 bf16 MFMA products per f32 product, f32 accumulate)",
                    peak_note="peak = 2500 TFLOP/s dense bf16 MFMA / 6 MFMA products per fp32 product"),
+    "fp16x2": dict(kernel="regress_h2_kernel", products=3, peak=PEAK_BF16_MFMA_TFLOPS / 3.0,
+                   dtype="f32-equivalent: fp16x2 (every f32 operand, scaled by an exact power of two, = sum of 2 fp16 planes to within "
+                         "2^-24 of its magnitude; 3 fp16 MFMA products per f32 product, f32 accumulate)",
+                   peak_note="peak = 2500 TFLOP/s dense fp16 MFMA / 3 MFMA products per fp32 product"),
     "f32": dict(kernel="regress_kernel", products=None, peak=PEAK_F32_MFMA_TFLOPS, dtype="f32",
                 peak_note="peak = 157.3 TFLOP/s dense fp32 MFMA"),
     "bf16x2": dict(kernel="regress_split_kernel", products=3, peak=PEAK_BF16_MFMA_TFLOPS / 3.0,

@@ -76,13 +76,19 @@ void p2p_regressor_destroy(p2p_regressor *reg);
  *                      bf16 numbers (24 significant bits), six v_mfma_f32_32x32x16_bf16 per product (all terms
  *                      down to 2^-16 of the product; the rest is below fp32 round-off), fp32 accumulation.
  *                      As accurate as P2P_REGRESS_F32 against an fp64 evaluation, ceiling 2.65x higher;
+ *   P2P_REGRESS_FP16X2 fp32-equivalent on the fp16 matrix cores: every fp32 operand, scaled by an exact power of two
+ *                      into the normal range of fp16, is the sum of two fp16 numbers to within 2^-24 of its
+ *                      magnitude; three v_mfma_f32_32x32x16_f16 per product (the dropped term is <= 2^-24 of it),
+ *                      fp32 accumulation; the scales are undone exactly.  As accurate as P2P_REGRESS_F32 against
+ *                      an fp64 evaluation, half the matrix-core work of P2P_REGRESS_BF16X3;
  *   P2P_REGRESS_BF16X2 reduced precision, opt-in only: two bf16 per operand (16 significant bits), three
  *                      products; regressed coordinates within ~2.5e-4 px of an fp64 evaluation.
- * New handles start in the mode named by the environment variable P2P_REGRESS_MODE ("f32" | "bf16x3" |
- * "bf16x2"), else P2P_REGRESS_DEFAULT.                                                          */
+ * New handles start in the mode named by the environment variable P2P_REGRESS_MODE ("f32" | "fp16x2" |
+ * "bf16x3" | "bf16x2"), else P2P_REGRESS_DEFAULT.                                               */
 #define P2P_REGRESS_F32     0
 #define P2P_REGRESS_BF16X2  1
 #define P2P_REGRESS_BF16X3  2
+#define P2P_REGRESS_FP16X2  3
 #define P2P_REGRESS_DEFAULT P2P_REGRESS_BF16X3
 int p2p_regressor_set_mode(p2p_regressor *reg, int mode);
 int p2p_regressor_get_mode(const p2p_regressor *reg);

@@ -83,7 +83,9 @@ struct p2p_regressor {
     const float *wp2;  // conv2 weights,                    [8][576][2][64][4]
     const float *ws1, *ws2;     // the same weights split into bf16 hi/lo planes in 32x32x16 fragment order
     const float *wx1, *wx2;     // the same weights split into three bf16 planes (24 significant bits)
-    int mode;                   // P2P_REGRESS_F32 | P2P_REGRESS_BF16X2 | P2P_REGRESS_BF16X3
+    const float *wh1, *wh2;     // the same weights, scaled per output channel, split into two fp16 planes
+    const float *bn1s_h, *bn2s_h;   // folded BN scales times the inverse of those weight (and activation) scales
+    int mode;                   // P2P_REGRESS_F32 | P2P_REGRESS_BF16X2 | P2P_REGRESS_BF16X3 | P2P_REGRESS_FP16X2
     const float *bn1s, *bn1b;   // folded BN scale/shift [512]
     const float *bn2s, *bn2b;   // [512]
     const float *fc1t, *fc1b, *bnf1s, *bnf1b;   // fc1 as [128][512][4]; [512]

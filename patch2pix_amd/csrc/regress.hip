@@ -344,19 +344,20 @@ static void fold_bn(const p2p_bn_params &bn, int n, float *scale, float *shift) 
 
 using namespace p2p;
 
-// Arithmetic of the two convolutions: the environment variable P2P_REGRESS_MODE ("f32" | "bf16x3" | "bf16x2")
+// Arithmetic of the two convolutions: the environment variable P2P_REGRESS_MODE ("f32" | "fp16x2" | "bf16x3" | "bf16x2")
 // picks the default for newly created regressors; p2p_regressor_set_mode overrides it per handle.
 static int default_regress_mode() {
     const char *e = std::getenv("P2P_REGRESS_MODE");
     if (e && std::strcmp(e, "f32") == 0) return P2P_REGRESS_F32;
     if (e && std::strcmp(e, "bf16x2") == 0) return P2P_REGRESS_BF16X2;
     if (e && std::strcmp(e, "bf16x3") == 0) return P2P_REGRESS_BF16X3;
+    if (e && std::strcmp(e, "fp16x2") == 0) return P2P_REGRESS_FP16X2;
     return P2P_REGRESS_DEFAULT;
 }
 
 extern "C" int p2p_regressor_set_mode(p2p_regressor *reg, int mode) {
     P2P_REQUIRE(reg, P2P_EINVAL, "p2p_regressor_set_mode: null handle");
-    P2P_REQUIRE(mode == P2P_REGRESS_F32 || mode == P2P_REGRESS_BF16X2 || mode == P2P_REGRESS_BF16X3, P2P_EINVAL, "p2p_regressor_set_mode: unknown mode %d", mode);
+    P2P_REQUIRE(mode == P2P_REGRESS_F32 || mode == P2P_REGRESS_BF16X2 || mode == P2P_REGRESS_BF16X3 || mode == P2P_REGRESS_FP16X2, P2P_EINVAL, "p2p_regressor_set_mode: unknown mode %d", mode);
     reg->mode = mode;
     return P2P_OK;
 }
@@ -378,7 +379,9 @@ extern "C" int p2p_regressor_create(const p2p_regressor_params *p, p2p_regressor
     const size_t o_wp1 = take(WP1_FLOATS), o_wp2 = take(WP2_FLOATS);
     const size_t o_ws1 = take(WS1_FLOATS), o_ws2 = take(WS2_FLOATS);
     const size_t o_wx1 = take(WX1_FLOATS), o_wx2 = take(WX2_FLOATS);
+    const size_t o_wh1 = take(WH1_FLOATS), o_wh2 = take(WH2_FLOATS);
     const size_t o_bn1s = take(512), o_bn1b = take(512), o_bn2s = take(512), o_bn2b = take(512);
+    const size_t o_bn1sh = take(512), o_bn2sh = take(512);
     const size_t o_fc1t = take(512 * 512), o_fc1b = take(512), o_bnf1s = take(512), o_bnf1b = take(512);
     const size_t o_fc2t = take(256 * 512), o_fc2b = take(256), o_bnf2s = take(256), o_bnf2b = take(256);
     const size_t o_fc3 = take(5 * 256), o_fc3b = take(8);
@@ -412,9 +415,17 @@ extern "C" int p2p_regressor_create(const p2p_regressor_params *p, p2p_regressor
                     }
         }
     pack_split_weights(p->conv1_w, p->conv2_w, &h[o_ws1], &h[o_ws2]);
-    pack_x3_weights(p->conv1_w, p->conv2_w, &h[o_wx1], &h[o_wx2]);
+    std::vector<int> t1(512), t2(512);
+    pack_x3_weights(p->conv1_w, p->conv2_w, &h[o_wx1], &h[o_wx2], t1.data(), t2.data());
+    pack_h2_weights(p->conv1_w, p->conv2_w, &h[o_wh1], &h[o_wh2], t1.data(), t2.data());
     fold_bn(p->bn1, 512, &h[o_bn1s], &h[o_bn1b]);
     fold_bn(p->bn2, 512, &h[o_bn2s], &h[o_bn2b]);
+    // fp16x2: conv1 accumulates 2^12 (activations) x 2^t1[n] (weights) x the true sum, conv2 2^t2[n] x (the per-proposal
+    // scale of H, undone in the kernel) x the true sum: exact powers of two folded into the BatchNorm scales
+    for (int n = 0; n < 512; ++n) {
+        h[o_bn1sh + n] = std::ldexp(h[o_bn1s + n], -12 - t1[n]);
+        h[o_bn2sh + n] = std::ldexp(h[o_bn2s + n], -t2[n]);
+    }
     fold_bn(p->bnf1, 512, &h[o_bnf1s], &h[o_bnf1b]);
     fold_bn(p->bnf2, 256, &h[o_bnf2s], &h[o_bnf2b]);
     // fc weights as [k/4][out][4] so that a wave reads 1 KiB contiguous per step
@@ -440,6 +451,8 @@ extern "C" int p2p_regressor_create(const p2p_regressor_params *p, p2p_regressor
     r->wp1 = dev + o_wp1; r->wp2 = dev + o_wp2;
     r->ws1 = dev + o_ws1; r->ws2 = dev + o_ws2;
     r->wx1 = dev + o_wx1; r->wx2 = dev + o_wx2;
+    r->wh1 = dev + o_wh1; r->wh2 = dev + o_wh2;
+    r->bn1s_h = dev + o_bn1sh; r->bn2s_h = dev + o_bn2sh;
     r->mode = default_regress_mode();
     r->bn1s = dev + o_bn1s; r->bn1b = dev + o_bn1b; r->bn2s = dev + o_bn2s; r->bn2b = dev + o_bn2b;
     r->fc1t = dev + o_fc1t; r->fc1b = dev + o_fc1b; r->bnf1s = dev + o_bnf1s; r->bnf1b = dev + o_bnf1b;
@@ -457,7 +470,7 @@ extern "C" void p2p_regressor_destroy(p2p_regressor *reg) {
 
 static RegDev to_dev(const p2p_regressor *r) {
     RegDev d;
-    d.wp1 = r->wp1; d.wp2 = r->wp2; d.ws1 = r->ws1; d.ws2 = r->ws2; d.wx1 = r->wx1; d.wx2 = r->wx2; d.bn1s = r->bn1s; d.bn1b = r->bn1b; d.bn2s = r->bn2s; d.bn2b = r->bn2b;
+    d.wp1 = r->wp1; d.wp2 = r->wp2; d.ws1 = r->ws1; d.ws2 = r->ws2; d.wx1 = r->wx1; d.wx2 = r->wx2; d.wh1 = r->wh1; d.wh2 = r->wh2; d.bn1s_h = r->bn1s_h; d.bn2s_h = r->bn2s_h; d.bn1s = r->bn1s; d.bn1b = r->bn1b; d.bn2s = r->bn2s; d.bn2b = r->bn2b;
     d.fc1t = r->fc1t; d.fc1b = r->fc1b; d.bnf1s = r->bnf1s; d.bnf1b = r->bnf1b;
     d.fc2t = r->fc2t; d.fc2b = r->fc2b; d.bnf2s = r->bnf2s; d.bnf2b = r->bnf2b; d.fc3 = r->fc3; d.fc3b = r->fc3b;
     return d;
@@ -529,7 +542,9 @@ static int regress_batch_impl(const p2p_regressor *reg1, const p2p_regressor *re
         a.matches[1] = adv(matches2, 4); a.probs[1] = adv(probs2, 1); a.raw[1] = adv(raw2, 5);
         if (n > 0) {
             int st;
-            if (reg1->mode == P2P_REGRESS_BF16X3) {
+            if (reg1->mode == P2P_REGRESS_FP16X2) {
+                st = launch_regress_h2(a, n, (hipStream_t)stream);
+            } else if (reg1->mode == P2P_REGRESS_BF16X3) {
                 st = launch_regress_x3(a, n, (hipStream_t)stream);
             } else if (reg1->mode == P2P_REGRESS_BF16X2) {
                 st = launch_regress_split(a, n, (hipStream_t)stream);

@@ -12,7 +12,9 @@ struct RegDev {
     const float *wp1, *wp2;             // f32 MFMA-fragment order (regress.hip)
     const float *ws1, *ws2;             // split-bf16 fragment order (regress_split.hip), viewed as 16-byte units
     const float *wx1, *wx2;             // three-plane bf16 fragment order (regress_x3.hip)
+    const float *wh1, *wh2;             // two-plane fp16 fragment order, per-channel power-of-two scales (regress_h2.hip)
     const float *bn1s, *bn1b, *bn2s, *bn2b;
+    const float *bn1s_h, *bn2s_h;       // BN scales with the fp16 operand scales of regress_h2.hip folded in
     const float *fc1t, *fc1b, *bnf1s, *bnf1b, *fc2t, *fc2b, *bnf2s, *bnf2b, *fc3, *fc3b;
 };
 
@@ -146,8 +148,15 @@ void split_conv1_index(int slab, int half, int j, int &ch, int &tap);   // K lay
 constexpr int XPF = 8;                   // units the weight prefetch may run past the end of a stream
 constexpr size_t WX1_FLOATS = (size_t)8 * (S1_UNITS + XPF) * 768;
 constexpr size_t WX2_FLOATS = (size_t)8 * (S2_UNITS + XPF) * 768;
-void pack_x3_weights(const float *conv1_w, const float *conv2_w, float *wx1, float *wx2);      // host
+// t1 / t2 [512]: per-output-channel exponents the weights were scaled by (all zero for the bf16 planes)
+void pack_x3_weights(const float *conv1_w, const float *conv2_w, float *wx1, float *wx2, int *t1, int *t2);      // host
 int launch_regress_x3(const RegressArgs &a, int n, hipStream_t stream);
+
+// regress_h2.hip: the same streams with two fp16 planes = 2 KiB per (wave, unit)
+constexpr size_t WH1_FLOATS = (size_t)8 * (S1_UNITS + XPF) * 512;
+constexpr size_t WH2_FLOATS = (size_t)8 * (S2_UNITS + XPF) * 512;
+void pack_h2_weights(const float *conv1_w, const float *conv2_w, float *wh1, float *wh2, int *t1, int *t2);      // host
+int launch_regress_h2(const RegressArgs &a, int n, hipStream_t stream);
 
 // host-side bf16 helpers (round to nearest even)
 static inline uint16_t bf16_rne(float f) {

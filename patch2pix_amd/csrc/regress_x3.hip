@@ -35,931 +35,14 @@
 //     slab ahead through a ring of four register buffers in conv1 and three slabs ahead through eight in conv2.
 //   * the halves of the work-group (waves 0-3 / 4-7; wave w shares its SIMD with wave w + 4) take turns on the matrix
 //     pipe between bare s_barriers: two MFMA-dense waves on one SIMD got 57 % of the pipe, one wave alone 85 %.
-#include "regress_common.h"
-
-#include <vector>
-
-namespace p2p {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// ---- LDS layout (bytes) --------------------------------------------------------------------------
-// conv1 phase, per image: level 1 as fp32 [81 cells][64 ch (+16 B pad)]; levels 2 and 3 as three bf16 planes
-// [plane][25 cells + a zero cell][64 ch (+16 B)] and [plane][9 cells + a zero cell][128 ch (+16 B)].  Then level 0 raw [img][3][256] and one
-// shared region that is, in turn: the fp32 copy of levels 2/3 the scale pass reads; the pre-scaled level-0 im2col
-// block A0[64 px][64 K fp32 (+16 B)] (K = img*32 + tap*3 + c, 27 real per image); the fold buffers
-// T2[4 wave pairs][28 level-2 rows][64 n] and T3[8 waves][9 level-3 rows][64 n] fp32.  Then the fold table [img][17][17] of {scale, T row offset} (row/column 0 =
-// the zero padding ring of the convolution) and the per-pixel scale [2][256].
-constexpr int XST1 = 64 * 4 + 16;                                 // bytes per level-1 cell
-constexpr int XNC1 = 81;
-constexpr int YST2 = 64 * 2 + 16, YNC2 = 25, YPL2 = (YNC2 + 1) * YST2;  // level 2: cell stride, cells (+ a zero cell), plane stride
-constexpr int YST3 = 128 * 2 + 16, YNC3 = 9, YPL3 = (YNC3 + 1) * YST3;  // level 3
-constexpr int XOFF1 = 0;
-constexpr int YOFF2 = XOFF1 + XNC1 * XST1;                        // 22032
-constexpr int YOFF3 = YOFF2 + 3 * YPL2;                           // 33264
-constexpr int XIMG = YOFF3 + 3 * YPL3;                            // 41424
-constexpr int XRAW0 = 2 * XIMG;                                   // float [2][3][256]
-constexpr int XSHARED = XRAW0 + 2 * 3 * 256 * 4;                  // 88992
-constexpr int XTMP2ST = 64 * 4 + 16, XTMP3ST = 128 * 4 + 16;      // fp32 copy of levels 2/3: [25][272] then [9][528]
-constexpr int XTMP3 = YNC2 * XTMP2ST, XTMPIMG = XTMP3 + YNC3 * XTMP3ST;
-constexpr int XA0ST = 64 * 4 + 16;
-constexpr int XTROWS = 28, XTROW = 64 * 4, XTW = XTROWS * XTROW;  // fold buffer of one wave
-constexpr int XTAB = XSHARED + 8 * XTW;                           // 146336
-constexpr int XTABIMG = 17 * 17 * 8;
-constexpr int XSM_SCALE = XTAB + 2 * XTABIMG + 16;                // float [2][256]
-constexpr int XCONV1B = XSM_SCALE + 512 * 4;
-// conv2 phase: the three planes of one 128-channel chunk of H, [plane][65 px][128 ch bf16 (+16 B)] (row 64 = zeros
-// = padding), and the chunks still to come as fp32 [3][64 px][128 ch (+16 B)].
-constexpr int HST = 128 * 2 + 16, HPL = 65 * HST;                 // 272, 17680
-constexpr int XPARK = 3 * HPL;                                    // 53040
-constexpr int XPARKST = 128 * 4 + 16, XPARKCH = 64 * XPARKST;     // 528, 33792
-constexpr int XCONV2B = XPARK + 3 * XPARKCH;                      // 154416
-// both phases
-constexpr int XSM_V = XCONV2B;
-constexpr int XSM_F1 = XSM_V + 512 * 4;
-constexpr int XSM_F2 = XSM_F1 + 512 * 4;
-constexpr int XSM_MISC = XSM_F2 + 256 * 4;
-constexpr int XSM_BYTES = XSM_MISC + 16 * 4;
-static_assert(2 * XTMPIMG <= 8 * XTW && 64 * XA0ST <= 8 * XTW, "the shared region is sized by the fold buffers");
-static_assert(XCONV1B <= XCONV2B, "conv1 buffers must end below the persistent block");
-static_assert(XIMG % 16 == 0 && YOFF2 % 16 == 0 && YOFF3 % 16 == 0 && YPL2 % 16 == 0 && YPL3 % 16 == 0 && XSHARED % 16 == 0 &&
-              XTAB % 16 == 0 && XSM_SCALE % 16 == 0 && HPL % 16 == 0 && XPARK % 16 == 0 && XCONV2B % 16 == 0,
-              "16-byte alignment of ds_read_b128");
-static_assert(XSM_BYTES <= 160 * 1024, "LDS budget");
-
-// two fp32 -> one dword of two bf16 (round to nearest even): v_cvt_pk_bf16_f32
-__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
-    const f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ unsigned short f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
-__device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
-
-// 8 consecutive K values of one row (two 16-byte LDS reads), scaled by s, as three bf16x8 planes
-__device__ __forceinline__ void split3(const f32x4 &xa, const f32x4 &xb, float s, f32x4 &p0, f32x4 &p1, f32x4 &p2) {
-#ifdef XP_NOSPLIT                       // timing experiment (wrong results): how much of the split is hidden
-    p0 = xa; p1 = xb; p2 = xa; return;
-#endif
-    const float x[8] = {xa[0] * s, xa[1] * s, xa[2] * s, xa[3] * s, xb[0] * s, xb[1] * s, xb[2] * s, xb[3] * s};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const unsigned h = pk_bf16(x[2 * q], x[2 * q + 1]);
-        const float r0 = x[2 * q] - __uint_as_float(h << 16);
-        const float r1 = x[2 * q + 1] - __uint_as_float(h & 0xffff0000u);
-        const unsigned m = pk_bf16(r0, r1);
-        const float t0 = r0 - __uint_as_float(m << 16);
-        const float t1 = r1 - __uint_as_float(m & 0xffff0000u);
-        p0[q] = __uint_as_float(h);
-        p1[q] = __uint_as_float(m);
-        p2[q] = __uint_as_float(pk_bf16(t0, t1));
-    }
-}
-
-#ifdef XF_PIN_W                         // timing experiment (wrong results): the weight stream never advances (always cache hits)
-#define XWADV(N)
-#else
-#define XWADV(N) wb += (N) * 3072;
-#endif
-#ifdef P2P_X3_TIMING                    // phase lengths in s_memtime ticks -> args.raw[0] (tools/x3_timing.py)
-#define XT_DECL unsigned long long xt_[14]; unsigned long long xt_last_;
-#define XT_START xt_last_ = __builtin_amdgcn_s_memtime(); for (int i_ = 0; i_ < 14; ++i_) xt_[i_] = 0;
-#define XT(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); xt_[i] += n_ - xt_last_; xt_last_ = n_; }
-#else
-#define XT_DECL
-#define XT_START
-#define XT(i)
-#endif
-#define XMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
-
-// raw fp32 A fragment (8 K values of this lane's row) of one m-tile: two 16-byte LDS reads
-#define XLOADR(R, P) R[0] = *(const f32x4 *)(P); R[1] = *(const f32x4 *)((P) + 16);
-// pre-split A fragment of one m-tile: one 16-byte LDS read per plane, PL = plane stride
-#define XLOADP(S, P, PL) S[0] = *(const f32x4 *)(P); S[1] = *(const f32x4 *)((P) + (PL)); S[2] = *(const f32x4 *)((P) + 2 * (PL));
-// weights of the unit `AHEAD` units after the current stream position: 3 planes
-// (wb = wave-uniform stream position, kept in SGPRs; wlane = 16 * lane: one VGPR addresses every weight load)
-#define XLOADB(BUF, AHEAD)                                                               \
-    { unsigned wo_ = (AHEAD) * 3072; P2P_OPAQUE_S(wo_);       /* opaque: keeps "+ AHEAD units" on the scalar side */  \
-      _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) BUF[q_] = *(const f32x4 *)((wb + wo_) + wlane + q_ * 1024); }
-// 12 MFMAs of one m-tile (planes SP) against the weights of both n-tiles: 6 products each, smallest terms first;
-// the two accumulators alternate.  XHALFZ starts the two accumulators from zero.
-#define XHALF_(C0IN, C1IN, CU0, CU1, SP, BU0, BU1)                                       \
-    CU0 = XMFMA(SP[2], BU0[0], C0IN); CU1 = XMFMA(SP[2], BU1[0], C1IN);                  \
-    CU0 = XMFMA(SP[1], BU0[1], CU0); CU1 = XMFMA(SP[1], BU1[1], CU1);                    \
-    CU0 = XMFMA(SP[0], BU0[2], CU0); CU1 = XMFMA(SP[0], BU1[2], CU1);                    \
-    CU0 = XMFMA(SP[1], BU0[0], CU0); CU1 = XMFMA(SP[1], BU1[0], CU1);                    \
-    CU0 = XMFMA(SP[0], BU0[1], CU0); CU1 = XMFMA(SP[0], BU1[1], CU1);                    \
-    CU0 = XMFMA(SP[0], BU0[0], CU0); CU1 = XMFMA(SP[0], BU1[0], CU1);
-#define XHALF(CU0, CU1, SP, BU0, BU1) XHALF_(CU0, CU1, CU0, CU1, SP, BU0, BU1)
-#define XHALFZ(CU0, CU1, SP, BU0, BU1) XHALF_(zero16, zero16, CU0, CU1, SP, BU0, BU1)
-
-// ---- slabs whose A operand is split in registers (conv1, levels 0 and 1) ---------------------------
-// Software pipeline inside a wave.  The matrix pipe takes 32 cycles per MFMA and a wave issues in order, so a wave
-// that first splits a whole slab and then issues its 24 MFMAs leaves the pipe idle while it -- and the other wave of
-// the SIMD, which runs the same code in step -- does VALU work.  Here every group of 12 MFMAs (one m-tile) carries
-// the split of the OTHER m-tile's next fragment in its shadow:
-//   phase A:  MFMAs of m-tile 0 (planes S0) || LDS read of the next slab's m-tile-0 fragment, split of R1 -> S1,
-//             weight loads of the next slab's first unit
-//   phase B:  MFMAs of m-tile 1 (planes S1) || LDS read of the next slab's m-tile-1 fragment, split of R0 -> S0,
-//             weight loads of the next slab's second unit
-// sched_group_barrier pins the interleave (1 MFMA, then up to 4 VALU; the loads at the head of the phase).
-// Weights: (BC0, BC1) = this slab's two units, (BN0, BN1) = the next slab's, loaded one slab ahead (>= 768 matrix-pipe
-// cycles) into the buffers the previous slab used.
-#ifndef XP_VALU
-#define XP_VALU 4                       // VALU operations placed behind each MFMA (tools/ab_variants.sh)
-#endif
-#define XPIPE(NDS)                                                                       \
-    __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0); __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);           \
-    _Pragma("unroll") for (int g_ = 0; g_ < 12; ++g_) {                                                              \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, XP_VALU, 0); }
-#define XPIPE0()                                                                         \
-    __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);                                                                \
-    _Pragma("unroll") for (int g_ = 0; g_ < 12; ++g_) {                                                              \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, XP_VALU, 0); }
-#define XSLAB(N0, N1, SC0, SC1, BC0, BC1, BN0, BN1, AH)                                   \
-    { XLOADR(R0, N0) XLOADB(BN0, AH) split3(R1[0], R1[1], (SC1), S1[0], S1[1], S1[2]);                               \
-      XHALF(acc00, acc01, S0, BC0, BC1) XPIPE(2) __builtin_amdgcn_sched_barrier(0);                                   \
-      XLOADR(R1, N1) XLOADB(BN1, (AH) + 1) split3(R0[0], R0[1], (SC0), S0[0], S0[1], S0[2]);                          \
-      XHALF(acc10, acc11, S1, BC0, BC1) XPIPE(2) __builtin_amdgcn_sched_barrier(0); }
-// Two consecutive slabs = four units.  On entry S0 holds the planes of the first slab's m-tile 0, R1 the raw
-// fragment of its m-tile 1 (XPRO), and B0/B1 the weights of its two units.  (N0,N1) = A addresses of the second
-// slab, (M0,M1) = of the slab after that.
-#define XSLAB2(N0, N1, M0, M1, SC0, SC1)                                                  \
-    { XSLAB(N0, N1, SC0, SC1, B0, B1, B2, B3, 2) XSLAB(M0, M1, SC0, SC1, B2, B3, B0, B1, 4) XWADV(4) }
-// The last slab of such a run: nothing to read or split for a next slab.
-#define XSLABEND(SC1, BC0, BC1, BN0, BN1, AH)                                            \
-    { XLOADB(BN0, AH) split3(R1[0], R1[1], (SC1), S1[0], S1[1], S1[2]);                                              \
-      XHALF(acc00, acc01, S0, BC0, BC1) XPIPE0() __builtin_amdgcn_sched_barrier(0);                                    \
-      XLOADB(BN1, (AH) + 1)                                                                                           \
-      XHALF(acc10, acc11, S1, BC0, BC1) XPIPE0() __builtin_amdgcn_sched_barrier(0); }
-// start of a run of slabs: fragments of its first slab
-#define XPRO(P0, P1, SC0) { XLOADR(R0, P0) XLOADR(R1, P1) split3(R0[0], R0[1], (SC0), S0[0], S0[1], S0[2]); }
-
-// ---- slabs whose A operand was split beforehand ------------------------------------------------------
-#define XLPIPE(NDS, NMFMA)                                                               \
-    __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0); __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);           \
-    __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
-// conv1, levels 2 + 3: one m-tile of cell rows -> T0/T1.  SC = planes of this slab, SN <- planes of the next (NP, NPL).
-#define XCSLAB(HALF, SC, SN, NP, NPL, BC0, BC1, BN0, BN1, AH)                             \
-    { XLOADP(SN, NP, NPL) XLOADB(BN0, AH) XLOADB(BN1, (AH) + 1)                                                       \
-      HALF(t0, t1, SC, BC0, BC1) XLPIPE(3, 12) __builtin_amdgcn_sched_barrier(0); }
-#ifndef XF_L3_32
-#define XF_L3_16 1
-#endif
-#ifdef XF_L3_16
-#if defined(XF_NO_PINGPONG) || defined(XF_CONV1_PAIR) || defined(XF_PPAR)
-#error "the 16-row level-3 path shares the T2 fold buffers between the halves of a SIMD pair: it needs the exclusive-turn protocol (add -DXF_L3_32 to these experiments)"
-#endif
-// Level 3 (9 cells per image) on 16-row tiles, v_mfma_f32_16x16x32_bf16 (A: lane l = row l & 15, K block
-// l >> 4; B: column l & 15; D: rows 4 * (l >> 4) + r, column l & 15).  One "pseudo-slab" = one K step of 32 channels
-// against two 16-column n-tiles = 12 MFMAs of 16 cycles and two weight units.
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-#define X16MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
-#define X16HALF_(C0IN, C1IN, CU0, CU1, SP, BU0, BU1)                                     \
-    CU0 = X16MFMA(SP[2], BU0[0], C0IN); CU1 = X16MFMA(SP[2], BU1[0], C1IN);              \
-    CU0 = X16MFMA(SP[1], BU0[1], CU0); CU1 = X16MFMA(SP[1], BU1[1], CU1);                \
-    CU0 = X16MFMA(SP[0], BU0[2], CU0); CU1 = X16MFMA(SP[0], BU1[2], CU1);                \
-    CU0 = X16MFMA(SP[1], BU0[0], CU0); CU1 = X16MFMA(SP[1], BU1[0], CU1);                \
-    CU0 = X16MFMA(SP[0], BU0[1], CU0); CU1 = X16MFMA(SP[0], BU1[1], CU1);                \
-    CU0 = X16MFMA(SP[0], BU0[0], CU0); CU1 = X16MFMA(SP[0], BU1[0], CU1);
-#define X16HALF(CU0, CU1, SP, BU0, BU1) X16HALF_(CU0, CU1, CU0, CU1, SP, BU0, BU1)
-#define X16HALFZ(CU0, CU1, SP, BU0, BU1) X16HALF_(zero4, zero4, CU0, CU1, SP, BU0, BU1)
-// LOADNEXT: the LDS reads this pseudo-slab carries for a later one (or nothing)
-#define X16SLAB(HALF, UA, UB, SC, LOADNEXT, BC0, BC1, BN0, BN1, AH)                       \
-    { LOADNEXT XLOADB(BN0, AH) XLOADB(BN1, (AH) + 1)                                                                  \
-      HALF(UA, UB, SC, BC0, BC1) __builtin_amdgcn_sched_barrier(0); }
-#endif
-// conv2: both m-tiles from the planes (AC0, AC1); (AN0, AN1) <- the next slab's (addresses NP0, NP1)
-// Two waves of a SIMD that both issue MFMAs back to back get ~57 % of the matrix pipe between them, one wave alone
-// 85 % (measured); so the two halves of the work-group take turns, two slabs (48 MFMAs) at a time: XPP() = the two
-// barriers that end a wave's turn and its partner's (a bare s_barrier: outstanding loads stay in flight).
-#ifdef XF_NO_PINGPONG
-#define XPP()
-#define XPB()
-#else
-#define XPB() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
-#define XPP() __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef XF_TURN4                         // experiment: four slabs per turn in conv2
-#define XPP2()
-#else
-#define XPP2() XPP()
-#endif
-// conv1 barrier protocol per step (see the loop): P0 before / P1 after the pixel range, C0 before / C1 after the cell
-// range, F after the fold.  Shipped: exclusive turns with staggered halves (waves 0-3: P | - | C | F, waves 4-7: - | C | F | P).
-#if defined(XF_NO_PINGPONG)
-#define XSTAGGER(g) (g)
-#define XPB_P0(st)
-#define XPB_P1()
-#define XPB_C0(g)
-#define XPB_C1(g)
-#define XPB_F(st, g)
-#elif defined(XF_CONV1_PAIR)            // experiment: halves aligned range against range (P beside C): worse
-#define XSTAGGER(g) (g)
-#define XPB_P0(st)
-#define XPB_P1() XPB()
-#define XPB_C0(g)
-#define XPB_C1(g)
-#define XPB_F(st, g) XPB()
-#elif defined(XF_PPAR)                  // experiment: both halves run the pixel range together, then take turns on the cell range
-#define XSTAGGER(g) 0
-#define XPB_P0(st)
-#define XPB_P1() XPB()
-#define XPB_C0(g) if (g) XPB()
-#define XPB_C1(g) XPB()
-#define XPB_F(st, g) if (!(g)) XPB()
-#else
-#define XSTAGGER(g) (g)
-#define XPB_P0(st) if (st) XPB()
-#define XPB_P1() XPB()
-#define XPB_C0(g) XPB()
-#define XPB_C1(g) XPB()
-#define XPB_F(st, g) if (!(st)) XPB()
-#endif
-// (the MFMAs lead: the first ones issue as soon as the turn starts, the loads for later slabs follow in their shadow)
-#ifndef XH_BURST                        // one load behind every MFMA: 2-3 % faster than two bursts of six at the head (XH_BURST);
-                                        // global loads first, alternating LDS/global loads, one load per two MFMAs: no better
-#define XHPIPE()                                                                         \
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                                \
-    _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                                                               \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }       \
-    _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                                                               \
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }       \
-    __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
-#else
-#define XHPIPE()                                                                         \
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);             \
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);             \
-    __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
-#endif
-#ifndef XH_NOSNAKE                      // MFMA order in which consecutive instructions share one operand and the four
-                                        // accumulators rotate (0.5 % faster than m-tile after m-tile: XH_NOSNAKE)
-#define XQUAD(AC0, AC1, BC0, BC1, P, Q)                                                  \
-    acc00 = XMFMA(AC0[P], BC0[Q], acc00); acc01 = XMFMA(AC0[P], BC1[Q], acc01);                                       \
-    acc11 = XMFMA(AC1[P], BC1[Q], acc11); acc10 = XMFMA(AC1[P], BC0[Q], acc10);
-#define XHMFMAS(AC0, AC1, BC0, BC1)                                                      \
-    XQUAD(AC0, AC1, BC0, BC1, 2, 0) XQUAD(AC0, AC1, BC0, BC1, 1, 0) XQUAD(AC0, AC1, BC0, BC1, 1, 1)                    \
-    XQUAD(AC0, AC1, BC0, BC1, 0, 1) XQUAD(AC0, AC1, BC0, BC1, 0, 2) XQUAD(AC0, AC1, BC0, BC1, 0, 0)
-#else
-#define XHMFMAS(AC0, AC1, BC0, BC1) XHALF(acc00, acc01, AC0, BC0, BC1) XHALF(acc10, acc11, AC1, BC0, BC1)
-#endif
-#define XHSLAB(AC0, AC1, AN0, AN1, NP0, NP1, BC0, BC1, BN0, BN1, AH)                       \
-    { XLOADP(AN0, NP0, HPL) XLOADP(AN1, NP1, HPL) XLOADB(BN0, AH) XLOADB(BN1, (AH) + 1)                                \
-      XHMFMAS(AC0, AC1, BC0, BC1)                                                                                     \
-      XHPIPE() __builtin_amdgcn_sched_barrier(0); }
-
-__global__ __launch_bounds__(NT, 2) void regress_x3_kernel(RegressArgs args) {
-    P2P_DYN_SHARED(unsigned char, smb);
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int prop = blockIdx.x;
-    int it = 0;
-    while (it + 1 < args.nitems && prop >= args.start[it + 1]) ++it;
-    if (args.dev_counts && prop - args.start[it] >= args.dev_counts[it]) return;      // empty slot (whole work-group)
-    const ItemDev &I = args.item[it];
-
-    float *raw0 = (float *)(smb + XRAW0);
-    float *scale = (float *)(smb + XSM_SCALE);
-    float *V = (float *)(smb + XSM_V);
-    float *F1 = (float *)(smb + XSM_F1);
-    float *F2 = (float *)(smb + XSM_F2);
-    float *misc = (float *)(smb + XSM_MISC);
-
-    if (tid < 4) {
-        float v;
-        if (args.is_float) v = ((const float *)args.proposals)[prop * 4 + tid];
-        else v = (float)((const long long *)args.proposals)[prop * 4 + tid];
-        misc[8 + tid] = v;
-    }
-    __syncthreads();
-
-#pragma unroll 1
-    for (int lvl = 0; lvl < args.nlevels; ++lvl) {
-        const RegDev &R_ = args.reg[lvl];
-        // window origins (x, y) in image 1 / image 2 (networks/utils.py:8-19); scalars + selects, never an indexed array
-        int moff = 8;                // opaque: the LDS address of misc is otherwise materialised before the loop and spilled
-        P2P_OPAQUE(moff);
-        const int xa = (int)misc[moff + 0] - 8, ya = (int)misc[moff + 1] - 8;
-        const int xb = (int)misc[moff + 2] - 8, yb = (int)misc[moff + 3] - 8;
-#define XX0(img_) ((img_) ? xb : xa)
-#define XY0(img_) ((img_) ? yb : ya)
-        __syncthreads();
-        // opaque copy of the thread id for the staging phases (keeps their lane-only index math inside the level loop)
-        int tidv = wave * 64 + P2P_LANE_ID();       // re-derived per level: not even the thread id is kept in a VGPR across it
-        P2P_OPAQUE(tidv);
-        // lane coordinates derived from the opaque copy: nothing lane-dependent is loop-invariant for the compiler, so
-        // nothing is hoisted out of the level loop and kept (or spilled) across its high-pressure phases
-        const int half = (tidv >> 5) & 1, l31 = tidv & 31;
-        XT_DECL XT_START
-        // waves 4-7 are the younger wave of their SIMD and lose the issue arbitration on every MFMA segment (they were
-        // ~20 % slower between barriers): static priority for that half, no per-segment flips
-        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-
-        // ------------------------------------------------------------ gather (networks/utils.py:4-36)
-        {
-            // two passes so that all ~40 scattered 4-byte loads of a thread are in flight together
-            float g0[2][2], g1[2][11], g2[2][4], g3[2][3];
-#pragma unroll
-            for (int img = 0; img < 2; ++img) {
-                const int Hh = I.H[img], Ww = I.W[img];
-                {
-                    const int r0 = clampi(XY0(img), 0, Hh - 1), c0 = clampi(XX0(img), 0, Ww - 1);
-                    const float *src = I.pyr[img][0];
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const int e = tidv + k * NT;
-                        const int c = e >> 8, rem = e & 255, r = rem >> 4, cc = rem & 15;
-                        g0[img][k] = (e < 768) ? src[((size_t)c * Hh + min(r0 + r, Hh - 1)) * Ww + min(c0 + cc, Ww - 1)] : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int j = 1; j < 4; ++j) {
-                    const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
-                    const int Cc = (j == 3) ? 128 : 64;
-                    const int nk = (j == 1) ? 11 : (j == 2) ? 4 : 3;
-                    const int Hj = Hh >> j, Wj = Ww >> j;                     // index clamp: dim // ds (networks/utils.py:22-23)
-                    const int Ha = level_dim(Hh, j), Wa = level_dim(Ww, j);  // extent of the backbone's map
-                    const int r0 = clampi(XY0(img) >> j, 0, Hj - 1);
-                    const int c0 = clampi(XX0(img) >> j, 0, Wj - 1);
-                    const float *src = I.pyr[img][j];
-#pragma unroll
-                    for (int k = 0; k < nk; ++k) {
-                        const int e = tidv + k * NT;
-                        const int c = e / (Rr * Rr);
-                        const int rem = e - c * (Rr * Rr);
-                        const int r = rem / Rr;
-                        const int cc = rem - r * Rr;
-                        const float v = (e < Cc * Rr * Rr)
-                                            ? src[((size_t)c * Ha + min(r0 + r, Hj - 1)) * Wa + min(c0 + cc, Wj - 1)] : 0.f;
-                        if (j == 1) g1[img][k] = v; else if (j == 2) g2[img][k] = v; else g3[img][k] = v;
-                    }
-                }
-            }
-#pragma unroll
-            for (int img = 0; img < 2; ++img) {
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int e = tidv + k * NT;
-                    if (e < 768) raw0[img * 768 + e] = g0[img][k];
-                }
-                unsigned char *tb = smb + img * XIMG;
-#pragma unroll
-                for (int j = 1; j < 4; ++j) {
-                    const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
-                    const int Cc = (j == 3) ? 128 : 64;
-                    const int nk = (j == 1) ? 11 : (j == 2) ? 4 : 3;
-#pragma unroll
-                    for (int k = 0; k < nk; ++k) {
-                        const int e = tidv + k * NT;
-                        if (e < Cc * Rr * Rr) {
-                            const int c = e / (Rr * Rr);
-                            const int rem = e - c * (Rr * Rr);
-                            const float v = (j == 1) ? g1[img][k] : (j == 2) ? g2[img][k] : g3[img][k];
-                            if (j == 1) {
-                                *(float *)(tb + XOFF1 + rem * XST1 + c * 4) = v;
-                            } else {
-                                // fp32 copy for the scale pass + the three bf16 planes (exact: v = p0 + p1 + p2)
-                                *(float *)(smb + XSHARED + img * XTMPIMG + ((j == 2) ? rem * XTMP2ST : XTMP3 + rem * XTMP3ST) + c * 4) = v;
-                                const unsigned short p0 = f2bf(v);
-                                const float r1 = v - bf2f(p0);
-                                const unsigned short p1 = f2bf(r1);
-                                const unsigned short p2 = f2bf(r1 - bf2f(p1));
-                                unsigned char *dst = tb + ((j == 2) ? YOFF2 + rem * YST2 : YOFF3 + rem * YST3) + c * 2;
-                                const int pl = (j == 2) ? YPL2 : YPL3;
-                                *(unsigned short *)dst = p0;
-                                *(unsigned short *)(dst + pl) = p1;
-                                *(unsigned short *)(dst + 2 * pl) = p2;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        if (tidv < 2 * 3 * (YST2 + YST3) / 16) {     // the zero cells: the dead rows 25-31 of the cell tile multiply zeros
-            const int per = (YST2 + YST3) / 16;
-            const int im = tidv / (3 * per), pl = (tidv / per) % 3, q = tidv % per;
-            float zf = 0.f;
-            P2P_OPAQUE(zf);
-            unsigned char *z = smb + im * XIMG + ((q < YST2 / 16) ? YOFF2 + pl * YPL2 + YNC2 * YST2 + q * 16
-                                                                  : YOFF3 + pl * YPL3 + YNC3 * YST3 + (q - YST2 / 16) * 16);
-            *(f32x4 *)z = (f32x4){zf, zf, zf, zf};
-        }
-        __syncthreads();
-        XT(0)
-
-        // ------------------------------------------------------------ per-pixel L2 scale (patch2pix.py:173-174) + fold table
-        {
-            const int img = tidv >> 8, pix = tidv & 255, py = pix >> 4, px = pix & 15;
-            const unsigned char *tb = smb + img * XIMG;
-            float ss = 0.f;
-            {
-                const float *p = raw0 + img * 768 + patch_cell(XY0(img), py, 0, I.H[img]) * 16 + patch_cell(XX0(img), px, 0, I.W[img]);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) ss = fmaf(p[c * 256], p[c * 256], ss);
-            }
-            const int c2 = patch_cell(XY0(img), py, 2, I.H[img]) * 5 + patch_cell(XX0(img), px, 2, I.W[img]);
-#pragma unroll
-            for (int j = 1; j < 4; ++j) {
-                const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
-                const int Cc = (j == 3) ? 128 : 64;
-                const int cj = patch_cell(XY0(img), py, j, I.H[img]) * Rr + patch_cell(XX0(img), px, j, I.W[img]);
-                const unsigned char *p = (j == 1) ? tb + XOFF1 + cj * XST1
-                                                  : smb + XSHARED + img * XTMPIMG + ((j == 2) ? cj * XTMP2ST : XTMP3 + cj * XTMP3ST);
-                for (int c = 0; c < Cc; c += 4) {
-                    const f32x4 v = *(const f32x4 *)(p + c * 4);
-                    ss = fmaf(v[0], v[0], ss); ss = fmaf(v[1], v[1], ss); ss = fmaf(v[2], v[2], ss); ss = fmaf(v[3], v[3], ss);
-                }
-            }
-            const float sc = 1.0f / sqrtf(ss + 1e-6f);
-            scale[tidv] = sc;
-            // fold table: entry (py + 1, px + 1) = {scale of the pixel, byte offset of its cell row in T}
-#ifdef XF_L3_16
-            const int c3 = patch_cell(XY0(img), py, 3, I.H[img]) * 3 + patch_cell(XX0(img), px, 3, I.W[img]);
-            *(f32x2 *)(smb + XTAB + img * XTABIMG + ((py + 1) * 17 + px + 1) * 8) =
-                (f32x2){sc, __int_as_float(c2 * XTROW | (c3 * XTROW) << 16)};
-#else
-            *(f32x2 *)(smb + XTAB + img * XTABIMG + ((py + 1) * 17 + px + 1) * 8) = (f32x2){sc, __int_as_float(c2 * XTROW)};
-#endif
-            if (tidv < 2 * 33) {     // ring = the zero padding of conv1: scale 0
-                const int im = tidv / 33, q = tidv - im * 33;
-                const int idx = (q < 17) ? q : (q - 16) * 17;
-                float zf = 0.f;      // opaque, or the constant is hoisted out of the level loop and spilled
-                P2P_OPAQUE(zf);
-                *(f32x2 *)(smb + XTAB + im * XTABIMG + idx * 8) = (f32x2){zf, zf};
-            }
-        }
-        __syncthreads();
-        XT(1)
-
-        // ------------------------------------------------------------ level-0 im2col block, pre-scaled
-        for (int e = tidv; e < 64 * 64; e += NT) {
-            const int m = e >> 6, kk = e & 63, img = kk >> 5, r = kk & 31;
-            float v = 0.f;
-            if (r < 27) {
-                const int tap = r / 3, c = r - tap * 3, ky = tap / 3, kx = tap - ky * 3;
-                const int py = 2 * (m >> 3) + ky - 1, px = 2 * (m & 7) + kx - 1;
-                if (py >= 0 && px >= 0)
-                    v = raw0[img * 768 + c * 256 + patch_cell(XY0(img), py, 0, I.H[img]) * 16 + patch_cell(XX0(img), px, 0, I.W[img])] *
-                        scale[img * 256 + py * 16 + px];
-            }
-            *(float *)(smb + XSHARED + m * XA0ST + kk * 4) = v;
-        }
-        __syncthreads();
-        XT(2)
-
-        // ------------------------------------------------------------ conv1: 3x3, stride 2, pad 1
-        // zeros from an opaque register: a literal zero gets tied to some long-lived zero of the prologue and spilled
-#define XZERO16(A_) { float z_ = 0.f; P2P_OPAQUE(z_); _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) A_[i_] = z_; }
-        f32x16 acc00, acc01, acc10, acc11;
-        XZERO16(acc00) XZERO16(acc01) XZERO16(acc10) XZERO16(acc11)
-        f32x4 B0[3], B1[3], B2[3], B3[3], S0[3], S1[3];
-        const f32x16 zero16 = {0};
-        {
-            f32x4 R0[2], R1[2];
-            const unsigned char *wb = (const unsigned char *)R_.wx1 + (size_t)wave * (S1_UNITS + XPF) * 3072;
-            const unsigned wlane = (tidv & 63) * 16;
-            XLOADB(B0, 0) XLOADB(B1, 1)
-            {   // level 0 of both images: 4 slabs of the pre-scaled block
-                const unsigned char *p0 = smb + XSHARED + l31 * XA0ST + half * 32;
-                const unsigned char *p1 = p0 + 32 * XA0ST;
-                XPRO(p0, p1, 1.0f)
-                XSLAB2(p0 + 64, p1 + 64, p0 + 128, p1 + 128, 1.0f, 1.0f)
-                XSLAB2(p0 + 192, p1 + 192, p0, p1, 1.0f, 1.0f)
-            }
-            __syncthreads();   // the im2col block is dead: its region becomes the fold buffers
-            XT(3)
-            // this lane's row of the cell tile: level-2 cell l31 (rows >= 25 are never read back) and its level-3 parent
-            const int c2y = (l31 < 25) ? l31 / 5 : 0, c2x = (l31 < 25) ? l31 - 5 * (l31 / 5) : 0;
-#ifdef XF_L3_16
-            // T2 (level-2 rows) is shared by wave w and w + 4: their folds never overlap under the turn protocol (G1's is
-            // over before e3, G0's runs between e3 and e4); T3 (9 level-3 rows) is private and written inside the C turn
-            float *Tw = (float *)(smb + XSHARED + (wave & 3) * XTW) + l31;
-            float *T3w = (float *)(smb + XSHARED + 4 * XTW + wave * (9 * XTROW));
-            const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
-#else
-            float *Tw = (float *)(smb + XSHARED + wave * XTW) + l31;
-#endif
-            // The K-ranges (tap, image) are walked in 18 steps.  A step = the pixel slabs of level 1 (P), the cell slabs
-            // of levels 2 + 3 (C) and the fold (F).  Waves 0-3 run P(i) C(i) F(i); waves 4-7 -- each shares its SIMD with
-            // one of waves 0-3 -- run C(i) F(i) P(i) (their weight stream is packed in that order), so that a fold, which
-            // issues no MFMA for ~1500 cycles, sits beside the other wave's MFMA-dense cell range instead of beside
-            // its fold.  In loop form: iteration it does P(it - stagger) then C(it) F(it).
-            // The two halves also take turns on the matrix pipe (see XPP): per step, waves 0-3 run P | - | C | F and
-            // waves 4-7 - | C | F | P between the same four barriers, so a fold always sits beside the partner's MFMAs.
-            const int stagger = XSTAGGER(wave >> 2), grp = wave >> 2; (void)grp;
-#pragma unroll 1
-            for (int it = 0; it < 18 + stagger; ++it) {
-                const int pi = it - stagger;
-                if (pi >= 0) {      // ---- P(pi): level 1 (64 ch), pixel rows, split in registers
-                    const int tap = pi >> 1, img = pi & 1;
-                    const int ky = tap / 3, kx = tap - ky * 3;
-                    // this lane's pixel rows (LDS byte offsets per m-tile) and their scale (zero for the padding ring:
-                    // the product is then exactly zero)
-                    int ab[2];
-                    float sc[2];
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int p = 32 * t + l31;
-                        const int py = 2 * (p >> 3) + ky - 1, px = 2 * (p & 7) + kx - 1;
-                        const bool ok = (py >= 0) && (px >= 0);
-                        const int pyc = max(py, 0), pxc = max(px, 0);
-                        const int cj = patch_cell(XY0(img), pyc, 1, I.H[img]) * 9 + patch_cell(XX0(img), pxc, 1, I.W[img]);
-                        ab[t] = img * XIMG + XOFF1 + cj * XST1 + half * 32;
-                        sc[t] = ok ? scale[img * 256 + pyc * 16 + pxc] : 0.f;
-                    }
-                    const unsigned char *a0 = smb + ab[0], *a1 = smb + ab[1];
-                    XPB_P0(stagger)
-#ifdef XF_SKIP_P                        // timing experiments (wrong results): XF_SKIP_P / _C / _FOLD / _CONV2 drop one part
-                    XWADV(8) (void)a0; (void)a1; (void)sc;
-#else
-                    XPRO(a0, a1, sc[0])
-                    XSLAB2(a0 + 64, a1 + 64, a0 + 128, a1 + 128, sc[0], sc[1])
-                    XSLAB(a0 + 192, a1 + 192, sc[0], sc[1], B0, B1, B2, B3, 2)
-                    XSLABEND(sc[1], B2, B3, B0, B1, 4)
-                    XWADV(4)
-#endif
-                    XPB_P1()
-                    XT(4)
-                }
-                if (it < 18) {      // ---- C(it), F(it): levels 2 (64 ch) + 3 (128 ch), cell rows, pre-split planes
-                    const int tap = it >> 1, img = it & 1;
-                    const int ky = tap / 3, kx = tap - ky * 3;
-                    // the lane's cell row.  Level-3 cell of level-2 cell c (per axis, absolute indices):
-                    // min(c >> 1, dim/8 - 1), see the header; the staged tiles start at the clamped origins.
-                    int a2, a3;
-                    {
-                        const int Hh = I.H[img], Ww = I.W[img];
-                        const int by2 = clampi(XY0(img) >> 2, 0, (Hh >> 2) - 1), bx2 = clampi(XX0(img) >> 2, 0, (Ww >> 2) - 1);
-                        const int by3 = clampi(XY0(img) >> 3, 0, (Hh >> 3) - 1), bx3 = clampi(XX0(img) >> 3, 0, (Ww >> 3) - 1);
-                        const int c3y = clampi(min((by2 + c2y) >> 1, (Hh >> 3) - 1) - by3, 0, 2);
-                        const int c3x = clampi(min((bx2 + c2x) >> 1, (Ww >> 3) - 1) - bx3, 0, 2);
-                        a2 = img * XIMG + YOFF2 + ((l31 < 25) ? c2y * 5 + c2x : YNC2) * YST2 + half * 16;
-                        a3 = img * XIMG + YOFF3 + ((l31 < 25) ? c3y * 3 + c3x : YNC3) * YST3 + half * 16;
-                    }
-                    const unsigned char *q2 = smb + a2, *q3 = smb + a3;
-                    f32x16 t0, t1;
-                    XPB_C0(grp)
-#if defined(XF_L3_16)
-                    {
-                        (void)q3;
-                        // level 3 first: 4 K steps of 32 channels x 4 n-tiles of 16 columns, rows = the 9 cells
-                        const int l16 = (tidv & 15), kb = (tidv >> 4) & 3;
-                        const unsigned char *q3r = smb + img * XIMG + YOFF3 + ((l16 < 9) ? l16 : YNC3) * YST3 + kb * 16;
-                        f32x4v u0, u1, u2, u3;
-                        XLOADP(S0, q3r, YPL3)
-                        X16SLAB(X16HALFZ, u0, u1, S0, XLOADP(S1, q3r + 64, YPL3), B0, B1, B2, B3, 2)
-                        X16SLAB(X16HALFZ, u2, u3, S0, , B2, B3, B0, B1, 4)
-                        XWADV(4)
-                        X16SLAB(X16HALF, u0, u1, S1, XLOADP(S0, q3r + 128, YPL3), B0, B1, B2, B3, 2)
-                        X16SLAB(X16HALF, u2, u3, S1, , B2, B3, B0, B1, 4)
-                        XWADV(4)
-                        X16SLAB(X16HALF, u0, u1, S0, XLOADP(S1, q3r + 192, YPL3), B0, B1, B2, B3, 2)
-                        X16SLAB(X16HALF, u2, u3, S0, , B2, B3, B0, B1, 4)
-                        XWADV(4)
-                        X16SLAB(X16HALF, u0, u1, S1, XLOADP(S0, q2, YPL2), B0, B1, B2, B3, 2)
-                        X16SLAB(X16HALF, u2, u3, S1, , B2, B3, B0, B1, 4)
-                        XWADV(4)
-                        // T3[row = 4 * kb + r][column 16 * nt + l16]
-                        P2P_WAVE_SYNC();
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (4 * kb + r < 9) {
-                                float *d = T3w + (4 * kb + r) * 64 + l16;
-                                d[0] = u0[r]; d[16] = u1[r]; d[32] = u2[r]; d[48] = u3[r];
-                            }
-                        // level 2: 4 slabs of 16 channels, rows = level-2 cells
-                        XCSLAB(XHALFZ, S0, S1, q2 + 32, YPL2, B0, B1, B2, B3, 2)
-                        XCSLAB(XHALF, S1, S0, q2 + 64, YPL2, B2, B3, B0, B1, 4)
-                        XWADV(4)
-                        XCSLAB(XHALF, S0, S1, q2 + 96, YPL2, B0, B1, B2, B3, 2)
-                        XCSLAB(XHALF, S1, S0, q2 + 96, YPL2, B2, B3, B0, B1, 4)
-                        XWADV(4)
-                    }
-#elif defined(XF_SKIP_C)
-                    t0 = acc00; t1 = acc01; XWADV(24) (void)q2; (void)q3;
-#else
-                    // 12 slabs of 16 channels = 32 bytes of bf16 per plane
-                    XLOADP(S0, q2, YPL2)
-                    XCSLAB(XHALFZ, S0, S1, q2 + 32, YPL2, B0, B1, B2, B3, 2)
-                    XCSLAB(XHALF, S1, S0, q2 + 64, YPL2, B2, B3, B0, B1, 4)
-                    XWADV(4)
-                    XCSLAB(XHALF, S0, S1, q2 + 96, YPL2, B0, B1, B2, B3, 2)
-                    XCSLAB(XHALF, S1, S0, q3, YPL3, B2, B3, B0, B1, 4)
-                    XWADV(4)
-#pragma unroll 1
-                    for (int g = 0; g < 4; ++g) {
-                        const int gn = (g < 3) ? 2 * g + 2 : 7;
-                        XCSLAB(XHALF, S0, S1, q3 + (2 * g + 1) * 32, YPL3, B0, B1, B2, B3, 2)
-                        XCSLAB(XHALF, S1, S0, q3 + gn * 32, YPL3, B2, B3, B0, B1, 4)
-                        XWADV(4)
-                    }
-#endif
-                    XPB_C1(grp)
-                    XT(5)
-#ifndef XF_SKIP_FOLD
-                    // fold: acc[pixel][n] += scale[pixel] * T[cell row of the pixel][n]
-                    P2P_WAVE_SYNC();            // the wave's previous fold has read T
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2);              // + 4 * half
-                        if (r < 12 || half == 0) {
-                            Tw[(row + 4 * half) * 64] = t0[r];
-                            Tw[(row + 4 * half) * 64 + 32] = t1[r];
-                        }
-                    }
-                    P2P_WAVE_SYNC();
-                    {
-                        const unsigned char *tabp = smb + XTAB + img * XTABIMG + (ky * 17 + kx + 8 * half) * 8;
-                        const unsigned char *Tr = (const unsigned char *)Tw;
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const f32x2 e = *(const f32x2 *)(tabp + ((8 * t + 2 * (r >> 2)) * 17 + 2 * (r & 3)) * 8);
-#ifdef XF_L3_16
-                                const int offs = __float_as_int(e[1]);
-                                const float *g = (const float *)(Tr + (offs & 0xffff));
-                                const float *h3 = (const float *)((const unsigned char *)(T3w + l31) + (offs >> 16));
-                                const float v0 = g[0] + h3[0], v1 = g[32] + h3[32];
-                                if (t == 0) { acc00[r] = fmaf(e[0], v0, acc00[r]); acc01[r] = fmaf(e[0], v1, acc01[r]); }
-                                else        { acc10[r] = fmaf(e[0], v0, acc10[r]); acc11[r] = fmaf(e[0], v1, acc11[r]); }
-#else
-                                const float *g = (const float *)(Tr + __float_as_int(e[1]));
-                                if (t == 0) { acc00[r] = fmaf(e[0], g[0], acc00[r]); acc01[r] = fmaf(e[0], g[32], acc01[r]); }
-                                else        { acc10[r] = fmaf(e[0], g[0], acc10[r]); acc11[r] = fmaf(e[0], g[32], acc11[r]); }
-#endif
-                                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // four rows in flight, not all 32
-                            }
-                    }
-#else
-                    acc00 += t0; acc01 += t1;
-#endif
-                    XPB_F(stagger, grp)
-                    XT(6)
-                }
-            }
-        }
-        __syncthreads();   // all waves are done reading the conv1 operands
-        XT(7)
-
-        // BN1; chunk 0 of H (channels of waves 0, 1) -> three planes, the other chunks wait as fp32
-        {
-            if (tidv < 3 * (HST / 16)) {     // the all-zero padding row of every plane
-                const int pl = tidv / (HST / 16), q = tidv - pl * (HST / 16);
-                float zf = 0.f;
-                P2P_OPAQUE(zf);
-                *(f32x4 *)(smb + pl * HPL + 64 * HST + q * 16) = (f32x4){zf, zf, zf, zf};
-            }
-            const int chunk = wave >> 1;
-            const int hv = half, lv = l31;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int n = wave * 64 + u * 32 + lv;
-                const int cc = (wave & 1) * 64 + u * 32 + lv;                // channel inside the chunk
-                const float s = R_.bn1s[n], b = R_.bn1b[n];
-                unsigned char *dplane = smb + 4 * hv * HST + cc * 2;
-                unsigned char *dpark = smb + XPARK + (chunk - 1) * XPARKCH + 4 * hv * XPARKST + cc * 4;
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const f32x16 &a = (t == 0) ? (u == 0 ? acc00 : acc01) : (u == 0 ? acc10 : acc11);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int p = 32 * t + (r & 3) + 8 * (r >> 2);       // + 4 * half
-                        const float v = fmaf(a[r], s, b);
-                        if (chunk == 0) {
-                            const unsigned short p0 = f2bf(v);
-                            const float r1 = v - bf2f(p0);
-                            const unsigned short p1 = f2bf(r1);
-                            const unsigned short p2 = f2bf(r1 - bf2f(p1));
-                            unsigned char *dst = dplane + p * HST;
-                            *(unsigned short *)dst = p0;
-                            *(unsigned short *)(dst + HPL) = p1;
-                            *(unsigned short *)(dst + 2 * HPL) = p2;
-                        } else {
-                            *(float *)(dpark + p * XPARKST) = v;
-                        }
-                    }
-                }
-            }
-        }
-
-        XT(8)
-        // ------------------------------------------------------------ conv2: 3x3, stride 1, pad 1, four K-chunks
-        XZERO16(acc00) XZERO16(acc01) XZERO16(acc10) XZERO16(acc11)
-        {
-            const unsigned char *wb = (const unsigned char *)R_.wx2 + (size_t)wave * (S2_UNITS + XPF) * 3072;
-            const unsigned wlane = (tidv & 63) * 16;
-            f32x4 A00[3], A01[3], A10[3], A11[3];          // [buffer][m-tile][plane]
-            // weights: ring of 8 units = 4 slabs, loaded THREE slabs ahead (a third of the stream misses L2 and comes
-            // from the Infinity Cache: ~1 us, more than the ~0.8 us one slab of both waves of the SIMD lasts)
-            f32x4 B4[3], B5[3], B6[3], B7[3];
-            XLOADB(B0, 0) XLOADB(B1, 1) XLOADB(B2, 2) XLOADB(B3, 3) XLOADB(B4, 4) XLOADB(B5, 5)
-#pragma unroll 1
-            for (int chunk = 0; chunk < 4; ++chunk) {
-                if (chunk > 0) {
-                    __syncthreads();       // everybody has read the previous chunk's planes
-                    // fp32 -> three planes, whole work-group: 64 px x 32 groups of 4 channels
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int e = tidv + k * NT, p = e >> 5, q = e & 31;
-                        const f32x4 v = *(const f32x4 *)(smb + XPARK + (chunk - 1) * XPARKCH + p * XPARKST + q * 16);
-                        unsigned pl0[2], pl1[2], pl2[2];
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const unsigned hh = pk_bf16(v[2 * h], v[2 * h + 1]);
-                            const float r0 = v[2 * h] - __uint_as_float(hh << 16);
-                            const float r1 = v[2 * h + 1] - __uint_as_float(hh & 0xffff0000u);
-                            const unsigned mm = pk_bf16(r0, r1);
-                            pl0[h] = hh;
-                            pl1[h] = mm;
-                            pl2[h] = pk_bf16(r0 - __uint_as_float(mm << 16), r1 - __uint_as_float(mm & 0xffff0000u));
-                        }
-                        unsigned char *dst = smb + p * HST + q * 8;
-                        *(f32x2 *)dst = (f32x2){__uint_as_float(pl0[0]), __uint_as_float(pl0[1])};
-                        *(f32x2 *)(dst + HPL) = (f32x2){__uint_as_float(pl1[0]), __uint_as_float(pl1[1])};
-                        *(f32x2 *)(dst + 2 * HPL) = (f32x2){__uint_as_float(pl2[0]), __uint_as_float(pl2[1])};
-                    }
-                }
-                __syncthreads();
-                XT(9)
-                // A addresses of a tap: pixel rows of the two m-tiles (row 64 = zeros outside the 8x8 map)
-                auto rows = [&](int tap, const unsigned char *&p0, const unsigned char *&p1) {
-                    const int ky = tap / 3, kx = tap - ky * 3;
-                    const int oy = (l31 >> 3) + ky - 1, ox = (l31 & 7) + kx - 1;
-                    const bool okx = (ox >= 0) && (ox < 8);
-                    const bool ok0 = okx && (oy >= 0);
-                    const bool ok1 = okx && (oy + 4 < 8);
-                    p0 = smb + (ok0 ? oy * 8 + ox : 64) * HST + half * 16;
-                    p1 = smb + (ok1 ? (oy + 4) * 8 + ox : 64) * HST + half * 16;
-                };
-                const unsigned char *p0, *p1;
-                rows(0, p0, p1);
-                XLOADP(A00, p0, HPL) XLOADP(A01, p1, HPL)
-#ifndef XF_NO_PINGPONG
-                if (wave >= 4) __builtin_amdgcn_s_barrier();        // waves 4-7 take the second turn
-#endif
-#ifdef XF_SKIP_CONV2
-                if (args.n < 0)
-#endif
-#ifdef XF_CONV2_HALF                    // timing experiment: only one wave per SIMD runs the conv2 loop
-                if (wave < 4)
-#endif
-#pragma unroll 1
-                for (int tap = 0; tap < 9; ++tap) {
-                    const unsigned char *n0, *n1;       // first slab of the next tap (of this chunk)
-                    rows(min(tap + 1, 8), n0, n1);
-                    // 8 slabs of 16 channels = 32 bytes per plane; slab j of a group of four loads the units of slab j + 3
-                    XHSLAB(A00, A01, A10, A11, p0 + 32, p1 + 32, B0, B1, B6, B7, 6)
-                    XHSLAB(A10, A11, A00, A01, p0 + 64, p1 + 64, B2, B3, B0, B1, 8)
-                    XPP2()
-                    XHSLAB(A00, A01, A10, A11, p0 + 96, p1 + 96, B4, B5, B2, B3, 10)
-                    XHSLAB(A10, A11, A00, A01, p0 + 128, p1 + 128, B6, B7, B4, B5, 12)
-                    XPP()
-                    XWADV(8)
-                    XHSLAB(A00, A01, A10, A11, p0 + 160, p1 + 160, B0, B1, B6, B7, 6)
-                    XHSLAB(A10, A11, A00, A01, p0 + 192, p1 + 192, B2, B3, B0, B1, 8)
-                    XPP2()
-                    XHSLAB(A00, A01, A10, A11, p0 + 224, p1 + 224, B4, B5, B2, B3, 10)
-                    XHSLAB(A10, A11, A00, A01, n0, n1, B6, B7, B4, B5, 12)
-                    XPP()
-                    XWADV(8)
-                    p0 = n0; p1 = n1;
-                }
-#ifndef XF_NO_PINGPONG
-                if (wave < 4) __builtin_amdgcn_s_barrier();         // every wave has executed the same number of barriers
-#endif
-                XT(10)
-            }
-        }
-
-        // BN2 -> ReLU -> max over the 8x8 outputs (BN before max: its scale may be negative)
-        {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int n = wave * 64 + u * 32 + l31;
-                const float s = R_.bn2s[n], b = R_.bn2b[n];
-                const f32x16 &aa = (u == 0) ? acc00 : acc01;
-                const f32x16 &ab2 = (u == 0) ? acc10 : acc11;
-                float m = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    m = fmaxf(m, fmaf(aa[r], s, b));
-                    m = fmaxf(m, fmaf(ab2[r], s, b));
-                }
-                m = fmaxf(m, __shfl_xor(m, 32));
-                if (half == 0) V[n] = m;
-            }
-        }
-        __syncthreads();
-        XT(11)
-
-        fc_tail_parse(R_, I, args, lvl, prop, tidv, V, F1, F2, misc);
-        XT(12)
-#ifdef P2P_X3_TIMING
-        // raw[0] doubles as the stamp buffer in timing builds: workgroups < 64 record [prop][wave][16] phase lengths
-        if (args.raw[0] && prop < 64 && (tidv & 63) == 0 && lvl == 0) {
-            float *dbg = args.raw[0] + 5 * args.n + (prop * 8 + wave) * 16;
-            for (int i = 0; i < 13; ++i) dbg[i] = (float)xt_[i];
-        }
-#endif
-    }
-}
-
-// --------------------------------------------------------------------------------------------------
-// host side: the weight streams.  conv1: units 0-7 = level 0 ([4 slabs][n-tile]), then [tap][img][16 slabs][n-tile]
-// (waves 4-7: the 12 cell slabs of a step before its 4 pixel slabs);
-// conv2: [chunk of 128 input channels][tap][8 slabs][n-tile].  A unit is [plane 3][lane 64][8 bf16]; K of a conv1
-// slab as in split_conv1_index.
-// --------------------------------------------------------------------------------------------------
-static void put3(uint16_t *d, size_t unit_base, int lane, int j, float v) {
-    const uint16_t p0 = bf16_rne(v);
-    const float r1 = v - bf16_to_f(p0);
-    const uint16_t p1 = bf16_rne(r1);
-    const uint16_t p2 = bf16_rne(r1 - bf16_to_f(p1));
-    d[(unit_base + lane) * 8 + j] = p0;
-    d[(unit_base + 64 + lane) * 8 + j] = p1;
-    d[(unit_base + 128 + lane) * 8 + j] = p2;
-}
-
-void pack_x3_weights(const float *conv1_w, const float *conv2_w, float *wx1, float *wx2) {
-    uint16_t *d1 = (uint16_t *)wx1, *d2 = (uint16_t *)wx2;
-    for (int w = 0; w < 8; ++w)
-        for (int pos = 0; pos < S1_SLABS; ++pos) {
-            // stream position -> canonical slab (split_conv1_index): waves 4-7 walk every (tap, image) step as
-            // [12 cell slabs of levels 2 + 3][4 pixel slabs of level 1], waves 0-3 the other way round
-            int slab = pos;
-#ifdef XF_PPAR
-            if (false) {
-#else
-            if (w >= 4 && pos >= 4) {
-#endif
-                const int step = (pos - 4) / 16, j = (pos - 4) % 16;
-                slab = 4 + step * 16 + ((j < 12) ? 4 + j : j - 12);
-            }
-#ifdef XF_L3_16
-            // inside a step the cell range is walked as [level 3: 8 pseudo-slabs in 16x16x32 order][level 2: 4 slabs]
-            if (slab >= 4) {
-                const int step = (slab - 4) / 16, sc = (slab - 4) % 16;       // canonical: 0-3 level 1, 4-7 level 2, 8-15 level 3
-                const int rel = (w >= 4) ? (pos - 4) % 16 : (pos - 4) % 16 - 4;   // position inside the cell range (waves 0-3: after P)
-                if (sc >= 4) {
-                    if (rel < 8) {          // pseudo-slab rel: K step rel / 2, n-tiles 2 * (rel & 1) + u
-                        const int ks = rel / 2, img = step & 1, tap = step >> 1;
-                        for (int u = 0; u < 2; ++u) {
-                            const size_t base = ((size_t)w * (S1_UNITS + XPF) + pos * 2 + u) * 192;
-                            const int nt = 2 * (rel & 1) + u;
-                            for (int lane = 0; lane < 64; ++lane)
-                                for (int j = 0; j < 8; ++j) {
-                                    const int n = 64 * w + 16 * nt + (lane & 15);
-                                    const int ch = img * 259 + 131 + 32 * ks + 8 * (lane >> 4) + j;
-                                    put3(d1, base, lane, j, conv1_w[((size_t)n * 518 + ch) * 9 + tap]);
-                                }
-                        }
-                        continue;
-                    }
-                    slab = 4 + step * 16 + 4 + (rel - 8);       // level-2 slab rel - 8
-                }
-            }
-#endif
-            for (int u = 0; u < 2; ++u) {
-                const int unit = pos * 2 + u;
-                const size_t base = ((size_t)w * (S1_UNITS + XPF) + unit) * 192;
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 8; ++j) {
-                        const int n = 64 * w + 32 * u + (lane & 31);
-                        int ch, tap;
-                        split_conv1_index(slab, lane >> 5, j, ch, tap);
-                        put3(d1, base, lane, j, (ch < 0) ? 0.f : conv1_w[((size_t)n * 518 + ch) * 9 + tap]);
-                    }
-            }
-        }
-    for (int w = 0; w < 8; ++w)
-        for (int slab = 0; slab < S2_SLABS; ++slab) {
-            const int chunk = slab / 72, tap = (slab % 72) / 8, sin = slab % 8;
-            for (int u = 0; u < 2; ++u) {
-                const int unit = slab * 2 + u;
-                const size_t base = ((size_t)w * (S2_UNITS + XPF) + unit) * 192;
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 8; ++j) {
-                        const int n = 64 * w + 32 * u + (lane & 31);
-                        const int ch = chunk * 128 + sin * 16 + 8 * (lane >> 5) + j;
-                        put3(d2, base, lane, j, conv2_w[((size_t)n * 512 + ch) * 9 + tap]);
-                    }
-            }
-        }
-}
-
-int launch_regress_x3(const RegressArgs &a, int n, hipStream_t stream) {
-    int dev = 0;
-    P2P_HIP_CHECK(hipGetDevice(&dev));
-    static bool attr_set[64] = {false};
-    if (dev < 64 && !attr_set[dev]) {
-        P2P_HIP_CHECK(hipFuncSetAttribute((const void *)regress_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)XSM_BYTES));
-        attr_set[dev] = true;
-    }
-    hipLaunchKernelGGL(regress_x3_kernel, dim3(n), dim3(NT), XSM_BYTES, stream, a);
-    return check_launch("regress_x3_kernel");
-}
-
-}  // namespace p2p
+#define XNPL 3
+#define XN_FP16 0
+#define XN_KERNEL regress_x3_kernel
+#define XN_LAUNCH launch_regress_x3
+#define XN_PACK pack_x3_weights
+#define XN_NAME "regress_x3_kernel"
+#define XN_W1 wx1
+#define XN_W2 wx2
+#define XN_BN1S bn1s
+#define XN_BN2S bn2s
+#include "regress_xn_impl.h"

@@ -87,6 +87,11 @@ static inline int atomicMax(int *p, int v) {
     while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
     return old;
 }
+static inline int atomicMin(int *p, int v) {
+    int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old > v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
 static inline float unsafeAtomicAdd(float *p, float v) {
     unsigned old = __atomic_load_n((unsigned *)p, __ATOMIC_RELAXED), want;
     float cur;
@@ -184,3 +189,46 @@ static inline hipemu_f32x4 hipemu_mfma_16x16x32_bf16(hipemu_bf16x8 a, hipemu_bf1
     return c;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) hipemu_mfma_16x16x32_bf16((a), (b), (c))
+
+// the fp16 forms of the two shapes (same lane layouts; products of fp16 are exact in fp32)
+typedef _Float16 hipemu_f16x8 __attribute__((ext_vector_type(8)));
+static inline hipemu_f32x16 hipemu_mfma_32x32x16_f16(hipemu_f16x8 a, hipemu_f16x8 b, hipemu_f32x16 c) {
+    struct { _Float16 a[8], b[8]; } mine;
+    memcpy(mine.a, &a, 16);
+    memcpy(mine.b, &b, 16);
+    const unsigned char *all = hipemu::wave_gather(&mine, sizeof(mine));
+    const int lane = hipemu::ctx().thread.x & 63, col = lane & 31, half = lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            _Float16 ua, ub;
+            memcpy(&ua, all + (row + 32 * (k >> 3)) * 32 + 2 * (k & 7), 2);
+            memcpy(&ub, all + (col + 32 * (k >> 3)) * 32 + 16 + 2 * (k & 7), 2);
+            acc += (float)ua * (float)ub;
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hipemu_mfma_32x32x16_f16((a), (b), (c))
+static inline hipemu_f32x4 hipemu_mfma_16x16x32_f16(hipemu_f16x8 a, hipemu_f16x8 b, hipemu_f32x4 c) {
+    struct { _Float16 a[8], b[8]; } mine;
+    memcpy(mine.a, &a, 16);
+    memcpy(mine.b, &b, 16);
+    const unsigned char *all = hipemu::wave_gather(&mine, sizeof(mine));
+    const int lane = hipemu::ctx().thread.x & 63, col = lane & 15, blk = lane >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * blk + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) {
+            _Float16 ua, ub;
+            memcpy(&ua, all + (row + 16 * (k >> 3)) * 32 + 2 * (k & 7), 2);
+            memcpy(&ub, all + (col + 16 * (k >> 3)) * 32 + 16 + 2 * (k & 7), 2);
+            acc += (float)ua * (float)ub;
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) hipemu_mfma_16x16x32_f16((a), (b), (c))

@@ -34,7 +34,7 @@ def ops():
     return ops
 
 
-MODES = ["bf16x3", "f32", "bf16x2"]       # default (fp32-equivalent), exact fp32 MFMA, reduced precision (opt-in)
+MODES = ["bf16x3", "fp16x2", "f32", "bf16x2"]   # fp32-equivalent (three bf16 planes / two fp16 planes), exact fp32 MFMA, reduced precision (opt-in)
 
 
 @pytest.fixture(scope="module")

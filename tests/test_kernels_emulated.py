@@ -84,7 +84,7 @@ def test_coarse_batch_equals_single_pairs(emu, ncn):
             assert torch.equal(m[i], m1[0]) and torch.equal(s[i], s1[0])
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "bf16x2", "f32"])
+@pytest.mark.parametrize("mode", ["fp16x2", "bf16x3", "bf16x2", "f32"])
 def test_regressors_against_reference_golden(mode, emu, sd):
     """Both regressor kernels (split-bf16 and exact fp32 MFMA) on the first proposals of the reference's
     forward_fine_match golden: integer proposals through the mid regressor, float proposals through the fine one."""
@@ -101,7 +101,7 @@ def test_regressors_against_reference_golden(mode, emu, sd):
         assert (out["probs1"] - torch.from_numpy(g[tag + "_probs"][:n])).abs().max() <= SCORE_TOL
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "bf16x2"])
+@pytest.mark.parametrize("mode", ["fp16x2", "bf16x3", "bf16x2"])
 def test_regressor_chain_and_image_borders(mode, emu, sd):
     """Mid -> fine inside one launch (the fine patch is centred on the truncated mid match, its base is the
     un-truncated one), with proposals on the image corners where every level of the patch clamps."""
@@ -124,7 +124,7 @@ def test_regressor_chain_and_image_borders(mode, emu, sd):
     assert (out["probs2"] - ref_finep).abs().max() <= SCORE_TOL
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "bf16x2"])
+@pytest.mark.parametrize("mode", ["fp16x2", "bf16x3", "bf16x2"])
 def test_regress_batch_items_of_different_sizes(mode, emu, sd):
     """p2p_regress_batch over items (pairs) of different image sizes, one of them empty == one call per item."""
     import ctypes
@@ -218,7 +218,7 @@ def test_coarse_stage_random_shapes(seed, emu, ncn, sd):
         assert torch.allclose(s[b], rs, rtol=1e-4)
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+@pytest.mark.parametrize("mode", ["fp16x2", "bf16x3", "f32"])
 def test_regressor_on_image_sizes_that_are_not_multiples_of_8(mode, emu, sd):
     """refine_matches loads images without rounding their size (utils/datasets/preprocess.py:7-30): the backbone's maps
     then have ceil(H / 2^j) rows, while the gather clamps to H // 2^j - 1 (networks/utils.py:22-23) -- the last row /
@@ -282,7 +282,7 @@ def test_device_filter_coarse_long_lists(n, distinct, emu):
     assert torch.equal(got[0][0], r) and torch.equal(got[0][1], rs)
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "bf16x2"])
+@pytest.mark.parametrize("mode", ["fp16x2", "bf16x3", "bf16x2"])
 def test_regress_with_device_counts(mode, emu, sd):
     """p2p_regress_batch_dev: every item owns `stride` slots, the first counts[i] hold proposals; used slots equal the
     per-item call bit for bit, the others are not touched."""
