@@ -89,7 +89,7 @@ void p2p_regressor_destroy(p2p_regressor *reg);
 #define P2P_REGRESS_BF16X2  1
 #define P2P_REGRESS_BF16X3  2
 #define P2P_REGRESS_FP16X2  3
-#define P2P_REGRESS_DEFAULT P2P_REGRESS_BF16X3
+#define P2P_REGRESS_DEFAULT P2P_REGRESS_FP16X2
 int p2p_regressor_set_mode(p2p_regressor *reg, int mode);
 int p2p_regressor_get_mode(const p2p_regressor *reg);
 

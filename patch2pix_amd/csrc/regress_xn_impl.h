@@ -119,9 +119,9 @@ __device__ __forceinline__ void splitn(const f32x4 &xa, const f32x4 &xb, float s
 #define XWADV(N) wb += (N) * XUB;
 #endif
 #ifdef P2P_X3_TIMING                    // phase lengths in s_memtime ticks -> args.raw[0] (tools/x3_timing.py)
-#define XT_DECL unsigned long long xt_[14]; unsigned long long xt_last_;
-#define XT_START xt_last_ = __builtin_amdgcn_s_memtime(); for (int i_ = 0; i_ < 14; ++i_) xt_[i_] = 0;
-#define XT(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); xt_[i] += n_ - xt_last_; xt_last_ = n_; }
+#define XT_DECL unsigned xt_[14]; unsigned xt_last_;      /* 32-bit tick differences: wave-uniform, kept in SGPRs */
+#define XT_START xt_last_ = (unsigned)__builtin_amdgcn_s_memtime(); _Pragma("unroll") for (int i_ = 0; i_ < 14; ++i_) xt_[i_] = 0;
+#define XT(i) { const unsigned n_ = (unsigned)__builtin_amdgcn_s_memtime(); xt_[i] += n_ - xt_last_; xt_last_ = n_; }
 #else
 #define XT_DECL
 #define XT_START
@@ -939,12 +939,17 @@ __global__ __launch_bounds__(NT, 2) void XN_KERNEL(RegressArgs args) {
         __syncthreads();
         XT(11)
 
+#ifdef XF_SKIP_FC                       // timing experiment (wrong results)
+        __syncthreads();
+#else
         fc_tail_parse(R_, I, args, lvl, prop, tidv, V, F1, F2, misc);
+#endif
         XT(12)
 #ifdef P2P_X3_TIMING
         // raw[0] doubles as the stamp buffer in timing builds: workgroups < 64 record [prop][wave][16] phase lengths
         if (args.raw[0] && prop < 64 && (tidv & 63) == 0 && lvl == 0) {
             float *dbg = args.raw[0] + 5 * args.n + (prop * 8 + wave) * 16;
+#pragma unroll
             for (int i = 0; i < 13; ++i) dbg[i] = (float)xt_[i];
         }
 #endif

@@ -69,7 +69,8 @@ class RegressorWeights:
         self.device = torch.device(device)
 
     def set_mode(self, mode):
-        """'bf16x3' (default: fp32-equivalent, three bf16 planes per operand), 'f32' (exact fp32 MFMA) or
+        """'fp16x2' (default: fp32-equivalent, two fp16 planes under exact power-of-two scales, 3 MFMA products), 'bf16x3'
+        (fp32-equivalent, three bf16 planes, 6 products), 'f32' (exact fp32 MFMA) or
         'bf16x2' (reduced precision, 16 significant bits; opt-in)."""
         _lib.check(_lib.p2p_regressor_set_mode(self.handle, _lib.REGRESS_MODES[mode]), "p2p_regressor_set_mode")
 

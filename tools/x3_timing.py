@@ -19,7 +19,8 @@ g1 = [t.to(dev) for t in p1[:4]]; g2 = [t.to(dev) for t in p2[:4]]
 pa, ka = ops._pyramid(g1); pb, kb = ops._pyramid(g2)
 m1 = torch.empty((n, 4), device=dev); q1 = torch.empty((n,), device=dev); m2 = torch.empty((n, 4), device=dev); q2 = torch.empty((n,), device=dev)
 raw = torch.zeros((5 * n + 64 * 8 * 16,), device=dev)
-mid.set_mode('bf16x3'); fine.set_mode('bf16x3')
+MODE = os.environ.get('MODE', 'fp16x2')
+mid.set_mode(MODE); fine.set_mode(MODE)
 for _ in range(3):
     _lib.check(_lib.p2p_regress(mid.handle, fine.handle, ctypes.byref(pa), ctypes.byref(pb), props.data_ptr(), 0, n,
                                 m1.data_ptr(), q1.data_ptr(), raw.data_ptr(), m2.data_ptr(), q2.data_ptr(), None,
@@ -34,4 +35,4 @@ for grp, sl in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
     for nme, v in zip(names, med):
         print(f"  {nme:20s} {v:9.0f}  ({100 * v / sum(med):4.1f} %)")
     print(f"  total                {sum(med):9.0f}")
-print("MFMA issue slots x 32 cycles x 2 waves per SIMD: level0 6144, P 110592, C 165888, conv2 442368")
+print("MFMA issue slots x 32 cycles x 2 waves per SIMD (bf16x3; fp16x2 = half): level0 6144, P 110592, C 165888, conv2 442368")
