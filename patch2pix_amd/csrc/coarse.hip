@@ -41,9 +41,11 @@ constexpr int KEY_NEG_INF = (int)0xff800000 ^ 0x7fffffff;
 // 1. L2 normalise + transpose to position-major with cell-major position order (modules.py:6)
 // ------------------------------------------------------------------------------------------------
 constexpr int PREP_P = 16;    // positions per work-group (300 groups at 60x80: fills the chip)
-// X3: write the normalised features as three bf16 planes [plane][pos'][C] (exact: v = p0 + p1 + p2) for
-// corr_pool_x3_kernel instead of fp32 [pos'][C]; the plane stride is hw * C elements.
-template <bool X3>
+// PLANES = 3: write the normalised features as three bf16 planes [plane][pos'][C] (exact: v = p0 + p1 + p2) for
+// corr_pool_xn_kernel instead of fp32 [pos'][C] (PLANES = 0); PLANES = 2: two fp16 planes of v * 2^12 (|v| <= 1, so both
+// planes stay in the normal range of fp16 and v * 2^12 = p0 + p1 to within 2^-24 |v * 2^12|).  The plane stride is hw * C elements.
+constexpr float CORR_FP16_SCALE = 4096.0f;
+template <int PLANES>
 __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ F, float *__restrict__ Fn, int C, int h,
                                                    int w, int k, size_t sF, size_t sFn) {
     F += blockIdx.z * sF;
@@ -88,8 +90,14 @@ __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ F, 
         const int pp = ((i / k) * wc + (j / k)) * (k * k) + (i % k) * k + (j % k);
         for (int c = tid; c < C; c += 256) {
             const float v = tile[c * (PREP_P + 1) + p] * inv[p];
-            if (!X3) {
+            if (PLANES == 0) {
                 Fn[(size_t)pp * C + c] = v;
+            } else if (PLANES == 2) {
+                unsigned short *d = (unsigned short *)Fn + (size_t)pp * C + c;
+                const float x = v * CORR_FP16_SCALE;
+                const _Float16 h0 = (_Float16)x;
+                d[0] = __builtin_bit_cast(unsigned short, h0);
+                d[(size_t)hw * C] = __builtin_bit_cast(unsigned short, (_Float16)(x - (float)h0));
             } else {
                 unsigned short *d = (unsigned short *)Fn + (size_t)pp * C + c;
                 const size_t pl = (size_t)hw * C;
@@ -111,7 +119,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ F, 
 // ------------------------------------------------------------------------------------------------
 constexpr int CT = 128;      // tile edge
 constexpr int CBK = 32;      // K per stage
-constexpr int CLD = 36;      // LDS row stride (floats): 16-B aligned, conflict-free for ds_read_b128
+constexpr int CLD = 36;      // LDS row stride (floats): 16-B aligned
 
 template <int KS>
 __global__ __launch_bounds__(256) void corr_pool_kernel(const float *__restrict__ A, const float *__restrict__ B,
@@ -209,20 +217,29 @@ __global__ __launch_bounds__(256) void corr_pool_kernel(const float *__restrict_
         }
 }
 
-// The same GEMM + pooling epilogue in fp32-equivalent arithmetic on the bf16 matrix cores (P2P_CORR_MODE=bf16x3, the
-// default): both operands arrive as three bf16 planes (prep_kernel<true>), a product is the six
-// v_mfma_f32_32x32x16_bf16 of order <= 2 (see regress_x3.hip), fp32 accumulation.  No VALU in the loop: per K = 16
-// slab and wave 12 ds_read_b128 and 24 MFMAs.  LDS: [A|B][plane][128 rows][32 K bf16 (+16 B pad)] = 60 KB.
+// The same GEMM + pooling epilogue in fp32-equivalent arithmetic on the 16-bit matrix cores: both operands arrive as NPL
+// planes (prep_kernel<NPL>).  NPL = 2 (P2P_CORR_MODE=fp16x2, the default): two fp16 planes of the features times 2^12,
+// three v_mfma_f32_32x32x16_f16 per product (a0 b0 + a0 b1 + a1 b0; the dropped a1 b1 is <= 2^-24 of the product), the
+// accumulators are scaled back by 2^-24 (exact) in the epilogue.  NPL = 3 (P2P_CORR_MODE=bf16x3): three bf16 planes, the
+// six products of order <= 2 (see regress_x3.hip).  fp32 accumulation, no VALU in the loop: per K = 16 slab and wave
+// 4 * NPL ds_read_b128 and 4 * (3 or 6) MFMAs.  The K loop is double buffered: the global loads of stage i + 1 are in
+// flight while stage i is multiplied out of LDS, one barrier per stage.
+// LDS: [stage 2][A|B][plane][128 rows][32 K 16-bit (+16 B pad)] = 80 KB (fp16x2) / 120 KB (bf16x3).
 typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
-constexpr int CX_ROW = 32 * 2 + 16;          // bytes per LDS row: 80 = 5 x 16 (odd multiple: conflict-free ds_read_b128)
+typedef _Float16 cf16x8 __attribute__((ext_vector_type(8)));
+constexpr int CX_ROW = 32 * 2 + 16;          // bytes per LDS row: 80 = 5 x 16 (odd multiple of 16 B: the 16 lanes of a ds_read_b128
+                                             // service group land on 16 different 16-byte slots of the 256-byte bank row)
 constexpr int CX_PLANE = CT * CX_ROW;        // 10240
-constexpr int CX_MAT = 3 * CX_PLANE;         // 30720
-#define CXMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cbf16x8, (a)), __builtin_bit_cast(cbf16x8, (b)), (c), 0, 0, 0)
+template <int NPL> __device__ __forceinline__ f32x16 cx_mfma(const f32x4 &a, const f32x4 &b, const f32x16 &c) {
+    if (NPL == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cf16x8, a), __builtin_bit_cast(cf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cbf16x8, a), __builtin_bit_cast(cbf16x8, b), c, 0, 0, 0);
+}
 
-template <int KS>
-__global__ __launch_bounds__(256) void corr_pool_x3_kernel(const unsigned short *__restrict__ A, const unsigned short *__restrict__ B,
+template <int KS, int NPL>
+__global__ __launch_bounds__(256) void corr_pool_xn_kernel(const unsigned short *__restrict__ A, const unsigned short *__restrict__ B,
                                                            int nA, int nB, int C, float *__restrict__ P,
                                                            uint8_t *__restrict__ delta, size_t sAB, size_t sP, size_t sDelta) {
+    constexpr int CX_MAT = NPL * CX_PLANE, CX_STAGE = 2 * CX_MAT;
     A += blockIdx.z * sAB * 2;               // sAB is in 4-byte words
     B += blockIdx.z * sAB * 2;
     P += blockIdx.z * sP;
@@ -242,10 +259,10 @@ __global__ __launch_bounds__(256) void corr_pool_x3_kernel(const unsigned short 
 
     // loader: per plane and matrix 128 rows x 64 B = 512 16-byte pieces: thread -> pieces tid and tid + 256
     const int lrow = tid >> 2, lq = tid & 3;
-    for (int k0 = 0; k0 < C; k0 += 32) {
-        f32x4 va[3][2], vb[3][2];
+    f32x4 va[NPL][2], vb[NPL][2];
+    auto load = [&](int k0) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int r = lrow + 64 * i;
@@ -253,37 +270,63 @@ __global__ __launch_bounds__(256) void corr_pool_x3_kernel(const unsigned short 
                 va[pl][i] = *(const f32x4 *)(A + pl * plA + (size_t)ra * C + k0 + lq * 8);
                 vb[pl][i] = *(const f32x4 *)(B + pl * plB + (size_t)rb * C + k0 + lq * 8);
             }
-        __syncthreads();                     // the previous stage has been consumed
+    };
+    auto store = [&](unsigned char *st) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int r = lrow + 64 * i;
-                *(f32x4 *)(cx + pl * CX_PLANE + r * CX_ROW + lq * 16) = va[pl][i];
-                *(f32x4 *)(cx + CX_MAT + pl * CX_PLANE + r * CX_ROW + lq * 16) = vb[pl][i];
+                *(f32x4 *)(st + pl * CX_PLANE + r * CX_ROW + lq * 16) = va[pl][i];
+                *(f32x4 *)(st + CX_MAT + pl * CX_PLANE + r * CX_ROW + lq * 16) = vb[pl][i];
             }
-        __syncthreads();
+    };
+    load(0);
+    store(cx);
+    __syncthreads();
+    const int nk = C / 32;
+    for (int it = 0; it < nk; ++it) {
+        const unsigned char *st = cx + (it & 1) * CX_STAGE;
+        if (it + 1 < nk) load((it + 1) * 32);          // in flight while this stage is multiplied
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {     // two slabs of 16 K
-            f32x4 a[2][3], b[2][3];
+            f32x4 a[2][NPL], b[2][NPL];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    a[i][pl] = *(const f32x4 *)(cx + pl * CX_PLANE + (wr * 64 + i * 32 + l31) * CX_ROW + kk * 32 + half * 16);
-                    b[i][pl] = *(const f32x4 *)(cx + CX_MAT + pl * CX_PLANE + (wc * 64 + i * 32 + l31) * CX_ROW + kk * 32 + half * 16);
+                for (int pl = 0; pl < NPL; ++pl) {
+                    a[i][pl] = *(const f32x4 *)(st + pl * CX_PLANE + (wr * 64 + i * 32 + l31) * CX_ROW + kk * 32 + half * 16);
+                    b[i][pl] = *(const f32x4 *)(st + CX_MAT + pl * CX_PLANE + (wc * 64 + i * 32 + l31) * CX_ROW + kk * 32 + half * 16);
                 }
             // smallest terms first; the four accumulators rotate
+            constexpr int NT = (NPL == 3) ? 6 : 3;
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {
-                const int pa = (t == 0) ? 2 : (t == 1 || t == 3) ? 1 : 0;
-                const int pb = (t == 0 || t == 3 || t == 5) ? 0 : (t == 1 || t == 4) ? 1 : 2;
+            for (int t = 0; t < NT; ++t) {
+                int pa, pb;
+                if (NPL == 3) {
+                    pa = (t == 0) ? 2 : (t == 1 || t == 3) ? 1 : 0;
+                    pb = (t == 0 || t == 3 || t == 5) ? 0 : (t == 1 || t == 4) ? 1 : 2;
+                } else {
+                    pa = (t == 0) ? 1 : 0;
+                    pb = (t == 1) ? 1 : 0;
+                }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = CXMFMA(a[i][pa], b[j][pb], acc[i][j]);
+                    for (int j = 0; j < 2; ++j) acc[i][j] = cx_mfma<NPL>(a[i][pa], b[j][pb], acc[i][j]);
             }
         }
+        if (it + 1 < nk) store(cx + ((it + 1) & 1) * CX_STAGE);     // the other stage: everybody left it at the last barrier
+        __syncthreads();
+    }
+    if (NPL == 2) {                          // the planes carried 2^12 each
+        constexpr float inv = 1.0f / (CORR_FP16_SCALE * CORR_FP16_SCALE);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
     }
 
     // accumulator element r of lane: row = (r&3) + 8*(r>>2) + 4*half, col = l31 (the epilogue of corr_pool_kernel)
@@ -328,14 +371,15 @@ __global__ __launch_bounds__(256) void corr_pool_x3_kernel(const unsigned short 
         }
 }
 
-// arithmetic of the correlation GEMM: bf16x3 (default, fp32-equivalent) or the exact fp32 MFMA (P2P_CORR_MODE=f32)
-static bool corr_x3() {
+// arithmetic of the correlation GEMM: number of 16-bit planes per operand -- 2 = fp16x2 (default, fp32-equivalent), 3 = bf16x3
+// (fp32-equivalent, P2P_CORR_MODE=bf16x3), 0 = the exact fp32 MFMA (P2P_CORR_MODE=f32)
+static int corr_planes() {
     static int mode = -1;
     if (mode < 0) {
         const char *e = getenv("P2P_CORR_MODE");
-        mode = (e && !strcmp(e, "f32")) ? 0 : 1;
+        mode = (e && !strcmp(e, "f32")) ? 0 : (e && !strcmp(e, "bf16x3")) ? 3 : 2;
     }
-    return mode == 1;
+    return mode;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -936,31 +980,43 @@ extern "C" int p2p_coarse_forward_batch(const float *featA, const float *featB, 
         int *rkey1 = (int *)(base + ws.keys), *ckey1 = rkey1 + nAc, *rkey2 = ckey1 + nBc, *ckey2 = rkey2 + nAc;
 
         const dim3 cgrid(ceil_div(nB, CT), ceil_div(nA, CT), nz);
-        if (corr_x3()) {
+        const int npl = corr_planes();
+        if (npl) {
             int dev = 0;
             P2P_HIP_CHECK(hipGetDevice(&dev));
             static bool attr_set_dev[64] = {false};      // per device: a process may drive several GPUs
             const bool attr_set = dev < 64 && attr_set_dev[dev];
+            const int lds = 2 * 2 * npl * CX_PLANE;      // two stages of [A|B][plane]
             if (!attr_set) {
-                P2P_HIP_CHECK(hipFuncSetAttribute((const void *)corr_pool_x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CX_MAT));
-                P2P_HIP_CHECK(hipFuncSetAttribute((const void *)corr_pool_x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CX_MAT));
+                P2P_HIP_CHECK(hipFuncSetAttribute((const void *)corr_pool_xn_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * CX_PLANE));
+                P2P_HIP_CHECK(hipFuncSetAttribute((const void *)corr_pool_xn_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * CX_PLANE));
+                P2P_HIP_CHECK(hipFuncSetAttribute((const void *)corr_pool_xn_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 12 * CX_PLANE));
+                P2P_HIP_CHECK(hipFuncSetAttribute((const void *)corr_pool_xn_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 12 * CX_PLANE));
                 if (dev < 64) attr_set_dev[dev] = true;
             }
-            hipLaunchKernelGGL(prep_kernel<true>, dim3(ceil_div(nA, PREP_P), 1, nz), dim3(256), 0, stream, fA, fnA, C, hA, wA, ksize,
-                               (size_t)C * nA, sWs);
-            hipLaunchKernelGGL(prep_kernel<true>, dim3(ceil_div(nB, PREP_P), 1, nz), dim3(256), 0, stream, fB, fnB, C, hB, wB, ksize,
-                               (size_t)C * nB, sWs);
+            const dim3 ga(ceil_div(nA, PREP_P), 1, nz), gb(ceil_div(nB, PREP_P), 1, nz);
+            if (npl == 2) {
+                hipLaunchKernelGGL(prep_kernel<2>, ga, dim3(256), 0, stream, fA, fnA, C, hA, wA, ksize, (size_t)C * nA, sWs);
+                hipLaunchKernelGGL(prep_kernel<2>, gb, dim3(256), 0, stream, fB, fnB, C, hB, wB, ksize, (size_t)C * nB, sWs);
+            } else {
+                hipLaunchKernelGGL(prep_kernel<3>, ga, dim3(256), 0, stream, fA, fnA, C, hA, wA, ksize, (size_t)C * nA, sWs);
+                hipLaunchKernelGGL(prep_kernel<3>, gb, dim3(256), 0, stream, fB, fnB, C, hB, wB, ksize, (size_t)C * nB, sWs);
+            }
             const unsigned short *pa = (const unsigned short *)fnA, *pb = (const unsigned short *)fnB;
-            if (ksize == 1)
-                hipLaunchKernelGGL(corr_pool_x3_kernel<1>, cgrid, dim3(256), 2 * CX_MAT, stream, pa, pb, nA, nB, C, P,
-                                   (uint8_t *)nullptr, sWs, sWs, (size_t)0);
+            uint8_t *dk = (ksize == 1) ? (uint8_t *)nullptr : dout;
+            const size_t sd = (ksize == 1) ? (size_t)0 : nel;
+            if (ksize == 1 && npl == 2)
+                hipLaunchKernelGGL((corr_pool_xn_kernel<1, 2>), cgrid, dim3(256), lds, stream, pa, pb, nA, nB, C, P, dk, sWs, sWs, sd);
+            else if (ksize == 1)
+                hipLaunchKernelGGL((corr_pool_xn_kernel<1, 3>), cgrid, dim3(256), lds, stream, pa, pb, nA, nB, C, P, dk, sWs, sWs, sd);
+            else if (npl == 2)
+                hipLaunchKernelGGL((corr_pool_xn_kernel<2, 2>), cgrid, dim3(256), lds, stream, pa, pb, nA, nB, C, P, dk, sWs, sWs, sd);
             else
-                hipLaunchKernelGGL(corr_pool_x3_kernel<2>, cgrid, dim3(256), 2 * CX_MAT, stream, pa, pb, nA, nB, C, P, dout, sWs,
-                                   sWs, nel);
+                hipLaunchKernelGGL((corr_pool_xn_kernel<2, 3>), cgrid, dim3(256), lds, stream, pa, pb, nA, nB, C, P, dk, sWs, sWs, sd);
         } else {
-            hipLaunchKernelGGL(prep_kernel<false>, dim3(ceil_div(nA, PREP_P), 1, nz), dim3(256), 0, stream, fA, fnA, C, hA, wA, ksize,
+            hipLaunchKernelGGL(prep_kernel<0>, dim3(ceil_div(nA, PREP_P), 1, nz), dim3(256), 0, stream, fA, fnA, C, hA, wA, ksize,
                                (size_t)C * nA, sWs);
-            hipLaunchKernelGGL(prep_kernel<false>, dim3(ceil_div(nB, PREP_P), 1, nz), dim3(256), 0, stream, fB, fnB, C, hB, wB, ksize,
+            hipLaunchKernelGGL(prep_kernel<0>, dim3(ceil_div(nB, PREP_P), 1, nz), dim3(256), 0, stream, fB, fnB, C, hB, wB, ksize,
                                (size_t)C * nB, sWs);
             if (ksize == 1)
                 hipLaunchKernelGGL(corr_pool_kernel<1>, cgrid, dim3(256), 0, stream, fnA, fnB, nA, nB, C, P, (uint8_t *)nullptr, sWs,

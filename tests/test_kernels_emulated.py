@@ -349,9 +349,9 @@ def test_match_tail_against_reference_semantics(emu):
 
 
 def test_correlation_modes_agree(tmp_path):
-    """The two arithmetic modes of the correlation GEMM (bf16x3 planes, the default, and the exact fp32 MFMA behind
-    P2P_CORR_MODE=f32) in separate processes (the mode is read once): same relocalisation argmaxes, same matches, pooled
-    volume equal to fp32 rounding."""
+    """The three arithmetic modes of the correlation GEMM (fp16x2 planes, the default; bf16x3 planes; the exact fp32 MFMA
+    behind P2P_CORR_MODE=f32) in separate processes (the mode is read once): same relocalisation argmaxes, same
+    matches, pooled volume equal to fp32 rounding."""
     import subprocess
     import sys
     code = r'''
@@ -367,10 +367,12 @@ torch.save((corr, delta, m, s), sys.argv[1])
 '''
     outs = {}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for mode in ("bf16x3", "f32"):
+    for mode in ("fp16x2", "bf16x3", "f32"):
         f = str(tmp_path / f"{mode}.pt")
         subprocess.check_call([sys.executable, "-c", code, f], env=dict(os.environ, P2P_CORR_MODE=mode), cwd=root)
         outs[mode] = torch.load(f)
-    a, b = outs["bf16x3"], outs["f32"]
-    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
-    assert torch.allclose(a[0], b[0], rtol=2e-4, atol=1e-9) and torch.allclose(a[3], b[3], rtol=1e-4)
+    b = outs["f32"]
+    for mode in ("fp16x2", "bf16x3"):
+        a = outs[mode]
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), mode
+        assert torch.allclose(a[0], b[0], rtol=2e-4, atol=1e-9) and torch.allclose(a[3], b[3], rtol=1e-4), mode
