@@ -120,6 +120,14 @@ int p2p_coarse_forward_batch(const float *featA, const float *featB, int batch, 
                              int wB, int ksize, const p2p_ncn *ncn, float *corr4d_out, uint8_t *delta_out,
                              void *workspace, size_t workspace_bytes, p2p_stream_t stream);
 
+/* NeighConsensus.forward -- reference networks/ncn/model.py:145-155 (kernel_sizes [3,3], channels [16,1]):
+ * y = net(x) + T(net(T(x))), net = Conv4d(1->16) + ReLU + Conv4d(16->1) + ReLU (conv4d.py:12-74), T = swap of the A and B axes,
+ * on `batch` volumes x [B, hA, wA, hB, wB] (fp32) -> y_out of the same shape.  One kernel on the fp16 matrix cores in
+ * fp32-equivalent arithmetic (the fp16 planes are scaled by the volume's largest magnitude, found first); the hidden
+ * 16-channel volume stays in LDS (csrc/consensus.hip).  workspace: 4 bytes per volume of device memory.          */
+int p2p_neigh_consensus_batch(const float *x, int batch, int hA, int wA, int hB, int wB, const p2p_ncn *ncn, float *y_out,
+                              void *workspace, size_t workspace_bytes, p2p_stream_t stream);
+
 /* Expand the packed relocalisation byte into the reference's four int64 tensors
  * (max_i, max_j, max_k, max_l of modules.py:24-28); `out` holds 4 consecutive planes of n int64. */
 int p2p_delta_unpack(const uint8_t *delta, size_t n, int ksize, int64_t *out, p2p_stream_t stream);

@@ -61,6 +61,9 @@ p2p_coarse_forward = _sig("p2p_coarse_forward", ctypes.c_int,
 p2p_coarse_forward_batch = _sig("p2p_coarse_forward_batch", ctypes.c_int,
                                 [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 7 +
                                 [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, c_stream])
+p2p_neigh_consensus_batch = _sig("p2p_neigh_consensus_batch", ctypes.c_int,
+                                 [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                                           ctypes.c_size_t, c_stream])
 p2p_delta_unpack = _sig("p2p_delta_unpack", ctypes.c_int,
                         [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, c_stream])
 p2p_coarse_matches = _sig("p2p_coarse_matches", ctypes.c_int,
@@ -93,7 +96,7 @@ REGRESS_MODES = {"f32": 0, "bf16x2": 1, "bf16x3": 2, "fp16x2": 3}
 
 EXPORTS = ["p2p_version", "p2p_last_error", "p2p_ncn_create", "p2p_ncn_destroy", "p2p_regressor_create",
            "p2p_regressor_destroy", "p2p_coarse_workspace_bytes", "p2p_coarse_forward", "p2p_coarse_forward_batch",
-           "p2p_delta_unpack", "p2p_coarse_matches", "p2p_coarse_matches_batch", "p2p_filter_coarse_workspace_bytes", "p2p_filter_coarse_batch", "p2p_match_tail_batch", "p2p_regress", "p2p_regress_batch", "p2p_regress_batch_dev", "p2p_regressor_set_mode",
+           "p2p_neigh_consensus_batch", "p2p_delta_unpack", "p2p_coarse_matches", "p2p_coarse_matches_batch", "p2p_filter_coarse_workspace_bytes", "p2p_filter_coarse_batch", "p2p_match_tail_batch", "p2p_regress", "p2p_regress_batch", "p2p_regress_batch_dev", "p2p_regressor_set_mode",
            "p2p_regressor_get_mode"]
 
 

@@ -385,9 +385,10 @@ static int corr_planes() {
 // ------------------------------------------------------------------------------------------------
 // 3. row / column maxima of an [nA][nB] matrix (the two torch.max of ncn/model.py:165-166)
 // ------------------------------------------------------------------------------------------------
+// n keys = -inf, followed by one word = 0 (float bits of max |X| after the first mutual matching, see mm_apply_kernel)
 __global__ void fill_keys_kernel(int *p, int n, size_t sKeys) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[blockIdx.z * sKeys + i] = KEY_NEG_INF;
+    if (i <= n) p[blockIdx.z * sKeys + i] = (i < n) ? KEY_NEG_INF : 0;
 }
 
 // column maxima: a thread owns one column over a 64-row chunk; chunks meet in an (order independent) atomicMax
@@ -429,16 +430,25 @@ __device__ __forceinline__ float mm_value(float x, float max_over_b, float max_o
 // (in place when out == X)
 __global__ __launch_bounds__(256) void mm_apply_kernel(const float *X, int nA, int nB, const int *__restrict__ rkey,
                                                        const int *__restrict__ ckey, float *out, size_t sX, size_t sKeys,
-                                                       size_t sOut, float *__restrict__ zero) {
+                                                       size_t sOut, float *__restrict__ zero, int *amax) {
     X += blockIdx.z * sX;
     rkey += blockIdx.z * sKeys;
     ckey += blockIdx.z * sKeys;
     out += blockIdx.z * sOut;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)nA * nB) return;
-    const int r = (int)(i / nB), c = (int)(i - (size_t)r * nB);
-    out[i] = mm_value(X[i], key2f(rkey[r]), key2f(ckey[c]));
-    if (zero) zero[blockIdx.z * sX + i] = 0.f;      // same index space: clears the accumulation target of consensus layer 2
+    float v = 0.f;
+    if (i < (size_t)nA * nB) {
+        const int r = (int)(i / nB), c = (int)(i - (size_t)r * nB);
+        v = mm_value(X[i], key2f(rkey[r]), key2f(ckey[c]));
+        out[i] = v;
+        if (zero) zero[blockIdx.z * sX + i] = 0.f;      // same index space: clears the accumulation target of the consensus layers
+    }
+    if (amax) {                                     // largest magnitude of the volume (the fused consensus kernel scales its fp16 planes by it)
+        float m = fabsf(v);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+        if ((threadIdx.x & 63) == 0) atomicMax(amax + blockIdx.z * sKeys, __float_as_int(m));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -893,9 +903,26 @@ static CoarseWs coarse_ws(int C, int hA, int wA, int hB, int wB, int k) {
     w.P = off; off += al(nAc * nBc * 4);
     w.Y = off; off += al(nAc * nBc * 4);
     w.H1 = off; off += al(32 * nAc * nBc * 4);
-    w.keys = off; off += al(2 * (nAc + nBc) * 4);
+    w.keys = off; off += al((2 * (nAc + nBc) + 1) * 4);      // row / column maxima of both mutual matchings + max |X|
     w.total = off;
     return w;
+}
+
+// consensus.hip
+void pack_nc_fused(const float *w1, const float *b1, const float *w2, std::vector<unsigned char> &out);
+int launch_nc_fused(const float *X, float *Y, size_t stride, int pairs, int d0, int d1, int d2, int d3, const unsigned char *w_dev,
+                    float b2, const int *xmax, size_t xmax_stride, hipStream_t stream);
+int launch_absmax(const float *x, size_t n, size_t stride, int pairs, int *out, size_t out_stride, hipStream_t stream);
+
+// the two consensus layers: "fused" (default: one kernel on the fp16 matrix cores, consensus.hip) or "valu" (the two fp32
+// VALU kernels above with the hidden volume in HBM, P2P_NC_MODE=valu)
+static bool nc_fused() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = getenv("P2P_NC_MODE");
+        mode = (e && !strcmp(e, "valu")) ? 0 : 1;
+    }
+    return mode == 1;
 }
 
 }  // namespace p2p
@@ -932,8 +959,20 @@ extern "C" int p2p_ncn_create(const float *w1, const float *b1, const float *w2,
         set_error("hipMemcpy of consensus weights failed: %s", hipGetErrorString(e));
         return P2P_EHIP;
     }
+    std::vector<unsigned char> wf;
+    pack_nc_fused(w1, b1, w2, wf);
+    unsigned char *wfd = nullptr;
+    e = hipMalloc(&wfd, wf.size());
+    if (e == hipSuccess) e = hipMemcpy(wfd, wf.data(), wf.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(dev);
+        if (wfd) (void)hipFree(wfd);
+        set_error("upload of the fused consensus weights failed: %s", hipGetErrorString(e));
+        return P2P_EHIP;
+    }
     p2p_ncn *n = new p2p_ncn();
     n->dev = dev; n->w1cat = dev; n->b1cat = dev + 81 * 32; n->w2m = dev + 81 * 32 + 32; n->b2 = b2[0];
+    n->wfused = wfd;
     *out = n;
     return P2P_OK;
 }
@@ -941,6 +980,7 @@ extern "C" int p2p_ncn_create(const float *w1, const float *b1, const float *w2,
 extern "C" void p2p_ncn_destroy(p2p_ncn *ncn) {
     if (!ncn) return;
     (void)hipFree(ncn->dev);
+    (void)hipFree(ncn->wfused);
     delete ncn;
 }
 
@@ -1026,31 +1066,37 @@ extern "C" int p2p_coarse_forward_batch(const float *featA, const float *featB, 
         }
 
         const int nkeys = 2 * (nAc + nBc);
-        hipLaunchKernelGGL(fill_keys_kernel, dim3(ceil_div(nkeys, 256), 1, nz), dim3(256), 0, stream, rkey1, nkeys, sWs);
+        hipLaunchKernelGGL(fill_keys_kernel, dim3(ceil_div(nkeys + 1, 256), 1, nz), dim3(256), 0, stream, rkey1, nkeys, sWs);
+        int *xmax = rkey1 + nkeys;
         const dim3 mgrid(ceil_div(nBc, 256), ceil_div(nAc, 64), nz);
         hipLaunchKernelGGL(colmax_kernel, mgrid, dim3(256), 0, stream, P, nAc, nBc, ckey1, sWs, sWs);
         hipLaunchKernelGGL(rowmax_kernel, dim3(ceil_div(nAc, 4), 1, nz), dim3(256), 0, stream, P, nAc, nBc, rkey1, sWs, sWs);
 
         // first mutual matching, in place on the pooled volume (also clears Y for layer 2's atomic adds)
         hipLaunchKernelGGL(mm_apply_kernel, dim3((unsigned)((nel + 255) / 256), 1, nz), dim3(256), 0, stream, P, nAc, nBc, rkey1,
-                           ckey1, P, sWs, sWs, sWs, Y);
-        const int ntiles = v.d0 * ceil_div(v.d1, L1_TB) * ceil_div(nBc, L1_Q);
-        const size_t lds1 = (size_t)3 * (L1_TB + 2) * l1_rows(v.d3) * (v.d3 + 2) * 4;
-        P2P_REQUIRE(lds1 <= 64 * 1024, P2P_EUNSUPPORTED, "p2p_coarse_forward: pooled width %d too large for the consensus tile", v.d3);
-        hipLaunchKernelGGL(nc_layer1_kernel, dim3(ntiles, 1, nz), dim3(256), lds1, stream, P, v, ncn->w1cat, ncn->b1cat, H1, sWs);
-        const NcTile nt = pick_nc_tile(v, (int)nz);
-        const int ntiles2 = ceil_div(v.d0, nt.ta) * ceil_div(v.d1, nt.tb) * ceil_div(v.d2, nt.tc) * ceil_div(v.d3, 8 * nt.tdr);
-        const size_t lds2 = nc_lds_bytes(nt);
-        if (nc_fullrow(v, nt))
-            hipLaunchKernelGGL(nc_layer2_kernel<true>, dim3(ntiles2, 2, nz), dim3(nt.nthreads), lds2, stream, H1, v, nt, ncn->w2m,
-                               ncn->b2, Y, sWs);
-        else
-            hipLaunchKernelGGL(nc_layer2_kernel<false>, dim3(ntiles2, 2, nz), dim3(nt.nthreads), lds2, stream, H1, v, nt, ncn->w2m,
-                               ncn->b2, Y, sWs);
+                           ckey1, P, sWs, sWs, sWs, Y, xmax);
+        if (nc_fused()) {
+            const int st = launch_nc_fused(P, Y, sWs, (int)nz, v.d0, v.d1, v.d2, v.d3, ncn->wfused, ncn->b2, xmax, sWs, stream);
+            if (st != P2P_OK) return st;
+        } else {
+            const int ntiles = v.d0 * ceil_div(v.d1, L1_TB) * ceil_div(nBc, L1_Q);
+            const size_t lds1 = (size_t)3 * (L1_TB + 2) * l1_rows(v.d3) * (v.d3 + 2) * 4;
+            P2P_REQUIRE(lds1 <= 64 * 1024, P2P_EUNSUPPORTED, "p2p_coarse_forward: pooled width %d too large for the consensus tile", v.d3);
+            hipLaunchKernelGGL(nc_layer1_kernel, dim3(ntiles, 1, nz), dim3(256), lds1, stream, P, v, ncn->w1cat, ncn->b1cat, H1, sWs);
+            const NcTile nt = pick_nc_tile(v, (int)nz);
+            const int ntiles2 = ceil_div(v.d0, nt.ta) * ceil_div(v.d1, nt.tb) * ceil_div(v.d2, nt.tc) * ceil_div(v.d3, 8 * nt.tdr);
+            const size_t lds2 = nc_lds_bytes(nt);
+            if (nc_fullrow(v, nt))
+                hipLaunchKernelGGL(nc_layer2_kernel<true>, dim3(ntiles2, 2, nz), dim3(nt.nthreads), lds2, stream, H1, v, nt, ncn->w2m,
+                                   ncn->b2, Y, sWs);
+            else
+                hipLaunchKernelGGL(nc_layer2_kernel<false>, dim3(ntiles2, 2, nz), dim3(nt.nthreads), lds2, stream, H1, v, nt, ncn->w2m,
+                                   ncn->b2, Y, sWs);
+        }
         hipLaunchKernelGGL(colmax_kernel, mgrid, dim3(256), 0, stream, Y, nAc, nBc, ckey2, sWs, sWs);
         hipLaunchKernelGGL(rowmax_kernel, dim3(ceil_div(nAc, 4), 1, nz), dim3(256), 0, stream, Y, nAc, nBc, rkey2, sWs, sWs);
         hipLaunchKernelGGL(mm_apply_kernel, dim3((unsigned)((nel + 255) / 256), 1, nz), dim3(256), 0, stream, Y, nAc, nBc, rkey2,
-                           ckey2, out, sWs, sWs, nel, (float *)nullptr);
+                           ckey2, out, sWs, sWs, nel, (float *)nullptr, (int *)nullptr);
     }
     return check_launch("coarse_forward kernels");
 }
@@ -1060,6 +1106,22 @@ extern "C" int p2p_coarse_forward(const float *featA, const float *featB, int C,
                                   void *workspace, size_t workspace_bytes, p2p_stream_t stream) {
     return p2p_coarse_forward_batch(featA, featB, 1, C, hA, wA, hB, wB, ksize, ncn, corr4d_out, delta_out, workspace,
                                     workspace_bytes, stream);
+}
+
+extern "C" int p2p_neigh_consensus_batch(const float *x, int batch, int hA, int wA, int hB, int wB, const p2p_ncn *ncn, float *y_out,
+                                         void *workspace, size_t workspace_bytes, p2p_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    P2P_REQUIRE(x && ncn && y_out && workspace, P2P_EINVAL, "p2p_neigh_consensus: null argument");
+    P2P_REQUIRE(batch >= 1 && batch <= 65535 && hA > 0 && wA > 0 && hB > 0 && wB > 0, P2P_EINVAL, "p2p_neigh_consensus: bad sizes");
+    P2P_REQUIRE(workspace_bytes >= (size_t)batch * sizeof(int), P2P_ENOMEM, "p2p_neigh_consensus: workspace of %zu bytes needed (4 per volume)",
+                (size_t)batch * sizeof(int));
+    const size_t nel = (size_t)hA * wA * hB * wB;
+    int *xmax = (int *)workspace;
+    P2P_HIP_CHECK(hipMemsetAsync(y_out, 0, (size_t)batch * nel * sizeof(float), stream));
+    P2P_HIP_CHECK(hipMemsetAsync(xmax, 0, (size_t)batch * sizeof(int), stream));
+    const int st = launch_absmax(x, nel, nel, batch, xmax, 1, stream);
+    if (st != P2P_OK) return st;
+    return launch_nc_fused(x, y_out, nel, batch, hA, wA, hB, wB, ncn->wfused, ncn->b2, xmax, 1, stream);
 }
 
 extern "C" int p2p_delta_unpack(const uint8_t *delta, size_t n, int ksize, int64_t *out, p2p_stream_t stream) {

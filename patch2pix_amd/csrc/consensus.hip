@@ -1,0 +1,360 @@
+// Neighbourhood consensus (reference networks/ncn/model.py:145-155, conv4d.py:12-74; 1 -> 16 -> 1 channels, kernel 3^4, both
+// symmetric branches) as ONE kernel on the fp16 matrix cores: the 16-channel hidden volume never leaves the compute unit.
+//
+// Work-group = one branch x one output tile [TA a][TB b][TC c][TD d] of the volume Y[a][b][c][d].  It walks the hidden
+// "strips" (a', b') that feed the tile, a' outer.  Per strip:
+//   S1  the 9 planes (da, db) of the input X (first MutualMatching applied) around the strip are staged in LDS as two fp16
+//       planes of X * 2^12 (|X| <= 1), rows c0-2 ... c0+TC+1, columns dt0-2 ... dt0+TD+1;
+//   S2  layer 1 on v_mfma_f32_32x32x16_f16: the hidden positions of the strip are FLAT (q = row * P + column, pitch P), an
+//       m-tile = 32 even positions, N = 16 channels x the position's two parities, K = 27 taps (da, db, dc) x a 4-wide
+//       window along d (the 3 taps dd of both parities): the A fragment of a lane is two aligned 8-byte reads of X, the
+//       weights (7 K-slabs, zero where a tap does not apply) live in registers.  bias + ReLU, zero outside the volume,
+//       hidden values as two fp16 planes [plane][8-channel half][position][8 channels] in LDS;
+//   S3  layer 2 on v_mfma_f32_16x16x32_f16 in "gather" form over the B taps: an m-tile = 16 flat OUTPUT positions, K = 9 taps
+//       (dc, dd) x 16 channels (every A fragment is one aligned 16-byte read of the hidden planes), N = the 9 taps (da, db):
+//       column n is this strip's contribution to the output plane (a' - da + 1, b' - db + 1), added to the tile's
+//       accumulators in LDS with ds_add_f32.  Inside a strip no two adds meet (different positions or different planes),
+//       strips are separated by barriers: the summation order of every output is fixed.
+// An output slice a is complete once hidden slice a + 1 is done: relu(sum + b2) is added to Y (zeroed beforehand; the two
+// branches are its two addends, so the result does not depend on which arrives first) and its accumulator slot recycled.
+//
+// Arithmetic: fp32-equivalent like the other 16-bit paths -- operands scaled by exact powers of two into the normal range of
+// fp16 and split into two planes (2^-24 relative), three MFMA products per fp32 product, fp32 accumulation; the scales
+// (2^12 on X, per-channel on the layer-1 weights, one per branch on the hidden planes and the layer-2 weights) are undone
+// exactly.  The halo of the tile is recomputed ((TA+2)(TB+2)(TC+2)/(TA TB TC) of layer 1); HBM sees X once per tile
+// neighbourhood (L2 hits) and Y once.
+#include "p2p_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace p2p {
+
+typedef _Float16 nh8 __attribute__((ext_vector_type(8)));
+typedef float nf4 __attribute__((ext_vector_type(4)));
+
+constexpr int NCF_THREADS = 256, NCF_WAVES = 4;
+constexpr int NCF_W1_BYTES = 7 * 2 * 64 * 16;      // layer-1 B fragments [slab][plane][lane][8 fp16]
+constexpr int NCF_W2_BYTES = 5 * 2 * 64 * 16;      // layer-2 B fragments [K step][plane][lane][8 fp16]
+constexpr int NCF_C_FLOATS = 64;                   // s1[16], b1[16], hscale, yunscale, padding
+constexpr int NCF_BRANCH_BYTES = NCF_W1_BYTES + NCF_W2_BYTES + NCF_C_FLOATS * 4;
+
+struct NcFusedArgs {
+    const float *X;          // [nA][nB] per pair
+    float *Y;                // [nA][nB] per pair, zero on entry
+    size_t stride;           // floats between pairs (both arrays)
+    int d0, d1, d2, d3;
+    int ta, tb, tc, td, P;   // tile, flat pitch (even, >= td + 4, <= 64)
+    int na, nb, nc, nd;      // tiles per axis
+    const unsigned char *w;  // [2 branches][NCF_BRANCH_BYTES]
+    float b2;
+    const int *xmax;         // per pair: float bits of max |X| (stride xmax_stride ints)
+    size_t xmax_stride;
+};
+
+__device__ __forceinline__ unsigned short nf2h(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+__device__ __forceinline__ float nh2f(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+#define NCF_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(nh8, (a)), __builtin_bit_cast(nh8, (b)), (c), 0, 0, 0)
+#define NCF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(nh8, (a)), __builtin_bit_cast(nh8, (b)), (c), 0, 0, 0)
+
+__global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a) {
+    P2P_DYN_SHARED(unsigned char, sm);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int br = blockIdx.y;
+    const float *X = a.X + (size_t)blockIdx.z * a.stride;
+    float *Y = a.Y + (size_t)blockIdx.z * a.stride;
+    int g = blockIdx.x;
+    const int dt0 = (g % a.nd) * a.td; g /= a.nd;
+    const int c0 = (g % a.nc) * a.tc; g /= a.nc;
+    const int b0 = (g % a.nb) * a.tb; g /= a.nb;
+    const int a0 = g * a.ta;
+    const int TA = a.ta, TB = a.tb, TC = a.tc, TD = a.td, P = a.P;
+    const int XROWS = TC + 4, HROWS = TC + 2, HN = HROWS * P + 2;
+    const int XPLANE = (9 * XROWS * P * 2 + 8 + 15) & ~15;   // bytes of one fp16 plane of the staged input (+ the window overrun of its
+                                                             // last position; the hidden planes behind it need 16-byte alignment)
+    const int HKH = HN * 16, HPLANE = 2 * HKH;               // hidden: [plane][channel half][position][8 x fp16]
+    const int YROW = TC * P, YSLOT = TB * YROW;              // accumulators: [3 slots][TB][TC * P] floats
+    unsigned char *Xs = sm;
+    unsigned char *Hs = sm + 2 * XPLANE;
+    float *Ya = (float *)(Hs + 2 * HPLANE);
+    const size_t nB = (size_t)a.d2 * a.d3;
+
+    // weights of this branch -> registers (they are the B operands of every MFMA of the kernel)
+    const unsigned char *wb = a.w + (size_t)br * NCF_BRANCH_BYTES;
+    nf4 w1[7][2], w2[5][2];
+#pragma unroll
+    for (int s = 0; s < 7; ++s)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) w1[s][p] = *(const nf4 *)(wb + ((s * 2 + p) * 64 + lane) * 16);
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) w2[s][p] = *(const nf4 *)(wb + NCF_W1_BYTES + ((s * 2 + p) * 64 + lane) * 16);
+    const float *cf = (const float *)(wb + NCF_W1_BYTES + NCF_W2_BYTES);
+    // The fp16 planes are laid out for |X| <= 1 (what MutualMatching makes of non-negative correlations).  A volume with
+    // larger values (negative correlations can do that) is scaled down by the power of two 2^E that brings its largest
+    // magnitude below 1; the hidden planes and the two un-scalings follow (all exact).
+    const int xeb = (a.xmax[(size_t)blockIdx.z * a.xmax_stride] >> 23) & 0xff;
+    const int E = min(max(xeb - 126, 0), 100);
+    const float up = __int_as_float((127 + E) << 23), down = __int_as_float((127 - E) << 23);
+    const float xscale = 4096.0f * down;
+    const float s1o = cf[lane & 15] * up, b1o = cf[16 + (lane & 15)], hscale = cf[32] * down, yun = cf[33] * up;
+
+    for (int i = tid; i < 3 * YSLOT; i += NCF_THREADS) Ya[i] = 0.f;
+    for (int i = tid; i < 2 * 2 * 2; i += NCF_THREADS) {     // the pad slots before and after the hidden positions stay zero
+        const int pl = i >> 2, kh = (i >> 1) & 1, end = i & 1;
+        *(nf4 *)(Hs + pl * HPLANE + kh * HKH + (end ? (HN - 1) * 16 : 0)) = (nf4){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+
+    const int a_hi = min(a0 + TA, a.d0);                     // outputs of the tile: [a0, a_hi)
+    const int ap_first = max(a0 - 1, 0), ap_last = min(a0 + TA, a.d0 - 1);
+    const int bp_first = max(b0 - 1, 0), bp_last = min(b0 + TB, a.d1 - 1);
+
+    auto flush = [&](int aout) {
+        // relu(sum + b2) of output slice aout -> Y; the slot becomes zero again
+        __syncthreads();
+        float *slot = Ya + (aout % 3) * YSLOT;
+        for (int r = wave; r < TB * TC; r += NCF_WAVES) {
+            const int bb = r / TC, ro = r - bb * TC;
+            const int ib = b0 + bb, ic = c0 + ro, id = dt0 + lane;
+            if (lane < TD && ib < a.d1 && ic < a.d2 && id < a.d3) {
+                const float v = fmaxf(slot[bb * YROW + ro * P + lane + 1] + a.b2, 0.f);
+                unsafeAtomicAdd(Y + ((size_t)aout * a.d1 + ib) * nB + (size_t)ic * a.d3 + id, v);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < YSLOT; i += NCF_THREADS) slot[i] = 0.f;
+    };
+
+    for (int ap = ap_first; ap <= ap_last; ++ap) {
+        for (int bp = bp_first; bp <= bp_last; ++bp) {
+            // ---------------- S1: the nine input planes around the strip, two fp16 planes of X * 2^12
+            for (int r = wave; r < 9 * XROWS; r += NCF_WAVES) {
+                const int pl9 = r / XROWS, xr = r - pl9 * XROWS;
+                const int ia = ap + pl9 / 3 - 1, ib = bp + pl9 % 3 - 1, ic = c0 - 2 + xr, id = dt0 - 2 + lane;
+                const bool ok = lane < P && ia >= 0 && ia < a.d0 && ib >= 0 && ib < a.d1 && ic >= 0 && ic < a.d2 && id >= 0 && id < a.d3;
+                const float v = ok ? X[((size_t)ia * a.d1 + ib) * nB + (size_t)ic * a.d3 + id] * xscale : 0.f;
+                if (lane < P) {
+                    const unsigned short h0 = nf2h(v);
+                    unsigned char *dst = Xs + (r * P + lane) * 2;
+                    *(unsigned short *)dst = h0;
+                    *(unsigned short *)(dst + XPLANE) = nf2h(v - nh2f(h0));
+                }
+            }
+            __syncthreads();
+            // ---------------- S2: layer 1 -> hidden planes
+            {
+                const int l31 = lane & 31, kb = lane >> 5, o = lane & 15, s = (lane >> 4) & 1;
+                const int nt1 = (HROWS * P + 63) >> 6;
+                for (int t = wave; t < nt1; t += NCF_WAVES) {
+                    const int q0 = t * 64;
+                    const int qh = min(q0 + 2 * l31, HROWS * P - 2);       // rows past the strip repeat its last row (never stored)
+                    f32x16 acc = {0};
+#pragma unroll
+                    for (int sl = 0; sl < 7; ++sl) {
+                        // the lane's two tap groups of this slab: g = 4 * sl + 2 * kb + {0, 1}; group 27 does not exist (zero weights)
+                        const int g0 = 4 * sl + 2 * kb, g1 = min(g0 + 1, 26);
+                        const int off0 = ((g0 / 3) * XROWS + g0 % 3) * P + qh, off1 = ((g1 / 3) * XROWS + g1 % 3) * P + qh;
+                        nf4 av[2];
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            const unsigned *x0 = (const unsigned *)(Xs + p * XPLANE + off0 * 2);
+                            const unsigned *x1 = (const unsigned *)(Xs + p * XPLANE + off1 * 2);
+                            av[p] = (nf4){__uint_as_float(x0[0]), __uint_as_float(x0[1]), __uint_as_float(x1[0]), __uint_as_float(x1[1])};
+                        }
+                        acc = NCF_MFMA32(av[1], w1[sl][0], acc);
+                        acc = NCF_MFMA32(av[0], w1[sl][1], acc);
+                        acc = NCF_MFMA32(av[0], w1[sl][0], acc);
+                    }
+                    // D: row i = (r & 3) + 8 (r >> 2) + 4 kb -> flat position q0 + 2 i + s, column n = (s, o)
+                    const int fl0 = q0 + 8 * kb + s;
+                    const int row0 = fl0 / P, col0 = fl0 - row0 * P;
+                    unsigned char *hdst = Hs + (o >> 3) * HKH + (o & 7) * 2 + 16;     // + 16: position -1 is slot 0
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int off = 2 * (r & 3) + 16 * (r >> 2);
+                        // (a tile of 64 positions spans at most three rows when P >= 28; tiny volumes divide)
+                        const int tcol = col0 + off;
+                        const int wrap = (P >= 28) ? (tcol >= P) + (tcol >= 2 * P) : tcol / P;
+                        const int col = tcol - wrap * P, rowh = row0 + wrap;
+                        const int ic = c0 - 1 + rowh, id = dt0 + col - 1;
+                        const bool ok = rowh < HROWS && col <= TD + 1 && ic >= 0 && ic < a.d2 && id >= 0 && id < a.d3;
+                        const float h = ok ? fmaxf(fmaf(acc[r], s1o, b1o), 0.f) * hscale : 0.f;
+                        if (rowh < HROWS) {
+                            const unsigned short h0 = nf2h(h);
+                            unsigned char *d = hdst + (fl0 + off) * 16;
+                            *(unsigned short *)d = h0;
+                            *(unsigned short *)(d + HPLANE) = nf2h(h - nh2f(h0));
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // ---------------- S3: layer 2, contributions of the strip to the 3 x 3 output planes around it
+            {
+                const int row = lane & 15, kb = lane >> 4, n = lane & 15;
+                const int da = n / 3, db = n - 3 * da;
+                const int aout = ap - da + 1, bout = bp - db + 1;
+                const bool lane_ok = n < 9 && aout >= a0 && aout < a_hi && bout >= b0 && bout < min(b0 + TB, a.d1);
+                float *ydst = Ya + ((aout + 3) % 3) * YSLOT + (bout - b0) * YROW;
+                const int nt2 = (TC * P + 15) >> 4;
+                for (int t = wave; t < nt2; t += NCF_WAVES) {
+                    const int q0 = t * 16;
+                    const int qo = min(q0 + row, TC * P - 1);
+                    nf4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int st = 0; st < 5; ++st) {
+                        const int tap = min(2 * st + (kb >> 1), 8);          // tap 9 does not exist (zero weights)
+                        const int dc = tap / 3, dd = tap - 3 * dc;
+                        const unsigned char *hp = Hs + (kb & 1) * HKH + (qo + dc * P + dd) * 16;   // hidden position qo + dc P + dd - 1, slot + 1
+                        const nf4 h0 = *(const nf4 *)hp, h1 = *(const nf4 *)(hp + HPLANE);
+                        acc = NCF_MFMA16(h1, w2[st][0], acc);
+                        acc = NCF_MFMA16(h0, w2[st][1], acc);
+                        acc = NCF_MFMA16(h0, w2[st][0], acc);
+                    }
+                    // D: row 4 kb + r = output position q0 + 4 kb + r, column n = plane (da, db)
+                    if (lane_ok) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int q = q0 + 4 * kb + r;
+                            if (q < TC * P) unsafeAtomicAdd(ydst + q, acc[r] * yun);
+                        }
+                    }
+                }
+            }
+        }
+        if (ap - 1 >= a0) flush(ap - 1);
+    }
+    if (ap_last < a_hi && ap_last >= a0) flush(ap_last);      // the volume ends inside the tile: its last slice has no slice above
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------
+static uint16_t h_f2h(float v) { return __builtin_bit_cast(uint16_t, (_Float16)v); }
+static float h_h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+static void put2(unsigned char *frag, int lane, int j, float v) {      // frag: [plane 2][lane 64][8 fp16]
+    uint16_t *d = (uint16_t *)frag;
+    const uint16_t h0 = h_f2h(v);
+    d[lane * 8 + j] = h0;
+    d[(64 + lane) * 8 + j] = h_f2h(v - h_h2f(h0));
+}
+static int pow2_exponent_to(float mx, int target) {      // t with mx * 2^t in [2^(target-1), 2^target)
+    if (!(mx > 0.f) || !std::isfinite(mx)) return 0;
+    int e;
+    std::frexp(mx, &e);
+    return target - e;
+}
+
+// w1 / w2 in the reference's stored layout (conv4d.py:119-120): w1s[da][o][0][db][dc][dd], w2s[da][0][c][db][dc][dd]
+void pack_nc_fused(const float *w1, const float *b1, const float *w2, std::vector<unsigned char> &out) {
+    out.assign(2 * NCF_BRANCH_BYTES, 0);
+    auto W1 = [&](int o, int da, int db, int dc, int dd) { return w1[(((da * 16 + o) * 3 + db) * 3 + dc) * 3 + dd]; };
+    auto W2 = [&](int c, int da, int db, int dc, int dd) { return w2[(((da * 16 + c) * 3 + db) * 3 + dc) * 3 + dd]; };
+    for (int br = 0; br < 2; ++br) {
+        // the transposed branch evaluates conv(x^T)^T: the same volume with A/B-swapped taps
+        auto W1b = [&](int o, int da, int db, int dc, int dd) { return br ? W1(o, dc, dd, da, db) : W1(o, da, db, dc, dd); };
+        auto W2b = [&](int c, int da, int db, int dc, int dd) { return br ? W2(c, dc, dd, da, db) : W2(c, da, db, dc, dd); };
+        unsigned char *base = out.data() + (size_t)br * NCF_BRANCH_BYTES;
+        int t1[16];
+        float hmax = 0.f, w2max = 0.f;
+        for (int o = 0; o < 16; ++o) {
+            float mx = 0.f, sum = std::fabs(b1[o]);
+            for (int t = 0; t < 81; ++t) {
+                const float v = W1b(o, t / 27, (t / 9) % 3, (t / 3) % 3, t % 3);
+                mx = std::max(mx, std::fabs(v));
+                sum += std::fabs(v);
+            }
+            t1[o] = pow2_exponent_to(mx, 12);
+            hmax = std::max(hmax, sum);                 // |hidden| <= sum |w| + |b| for |X| <= 1
+            for (int t = 0; t < 81; ++t) w2max = std::max(w2max, std::fabs(W2b(o, t / 27, (t / 9) % 3, (t / 3) % 3, t % 3)));
+        }
+        const int sh = pow2_exponent_to(2.f * hmax, 13), t2 = pow2_exponent_to(w2max, 12);
+        // layer 1: k = slab * 16 + 8 * (lane >> 5) + j = 4 g + e, g = (da, db, dc), e = window column; n = lane & 31 = (s, o)
+        for (int sl = 0; sl < 7; ++sl)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int k = sl * 16 + 8 * (lane >> 5) + j, gq = k >> 2, e = k & 3;
+                    const int n = lane & 31, o = n & 15, s = n >> 4, dd = e - s;
+                    float v = 0.f;
+                    if (gq < 27 && dd >= 0 && dd <= 2) v = std::ldexp(W1b(o, gq / 9, (gq / 3) % 3, gq % 3, dd), t1[o]);
+                    put2(base + sl * 2 * 64 * 16, lane, j, v);
+                }
+        // layer 2: k = step * 32 + 8 * (lane >> 4) + j: tap (dc, dd) = 2 step + (lane >> 5), channel 8 ((lane >> 4) & 1) + j; n = lane & 15 = (da, db)
+        for (int st = 0; st < 5; ++st)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int kb = lane >> 4, tap = 2 * st + (kb >> 1), ch = 8 * (kb & 1) + j, n = lane & 15;
+                    float v = 0.f;
+                    if (tap < 9 && n < 9) v = std::ldexp(W2b(ch, n / 3, n % 3, tap / 3, tap % 3), t2);
+                    put2(base + NCF_W1_BYTES + st * 2 * 64 * 16, lane, j, v);
+                }
+        float *cf = (float *)(base + NCF_W1_BYTES + NCF_W2_BYTES);
+        for (int o = 0; o < 16; ++o) {
+            cf[o] = std::ldexp(1.f, -12 - t1[o]);      // accumulators of layer 1 carry 2^12 (X) x 2^t1[o] (weights)
+            cf[16 + o] = b1[o];
+        }
+        cf[32] = std::ldexp(1.f, sh);                  // hidden values are stored times 2^sh
+        cf[33] = std::ldexp(1.f, -sh - t2);            // accumulators of layer 2 carry 2^sh x 2^t2
+    }
+}
+
+size_t nc_fused_lds_bytes(int tb, int tc, int P) {
+    return (size_t)2 * ((9 * (tc + 4) * P * 2 + 8 + 15) & ~15) + (size_t)2 * 2 * ((tc + 2) * P + 2) * 16 + (size_t)3 * tb * tc * P * 4;
+}
+
+// float bits of max |x| over n values per pair -> out[pair * out_stride] (zero beforehand); one atomic per wave
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, size_t n, size_t stride, int *out, size_t out_stride) {
+    x += (size_t)blockIdx.z * stride;
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0) atomicMax(out + (size_t)blockIdx.z * out_stride, __float_as_int(m));
+}
+
+int launch_absmax(const float *x, size_t n, size_t stride, int pairs, int *out, size_t out_stride, hipStream_t stream) {
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 2047) / 2048, 256);
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks, 1, pairs), dim3(256), 0, stream, x, n, stride, out, out_stride);
+    return check_launch("absmax_kernel");
+}
+
+int launch_nc_fused(const float *X, float *Y, size_t stride, int pairs, int d0, int d1, int d2, int d3, const unsigned char *w_dev,
+                    float b2, const int *xmax, size_t xmax_stride, hipStream_t stream) {
+    NcFusedArgs a{};
+    a.X = X; a.Y = Y; a.stride = stride; a.d0 = d0; a.d1 = d1; a.d2 = d2; a.d3 = d3; a.w = w_dev; a.b2 = b2;
+    a.xmax = xmax; a.xmax_stride = xmax_stride;
+    // tile: the B row in pieces of <= 60 columns; (TB, TC) as large as two work-groups per compute unit allow; TA splits the
+    // march until the launch has a few work-groups per compute unit
+    a.nd = ceil_div(d3, 60);
+    a.td = ceil_div(d3, a.nd);
+    a.P = (a.td + 4 + 1) & ~1;
+    a.tb = 6; a.tc = 6;
+    if (const char *e = getenv("P2P_NCF_TILE")) {       // experiments: "ta,tb,tc"
+        int ta = 0, tb = 0, tc = 0;
+        if (sscanf(e, "%d,%d,%d", &ta, &tb, &tc) == 3 && tb > 0 && tc > 0) { a.tb = tb; a.tc = tc; a.ta = ta; }
+    }
+    a.tb = std::min(a.tb, d1); a.tc = std::min(a.tc, d2);
+    a.nb = ceil_div(d1, a.tb); a.nc = ceil_div(d2, a.tc);
+    if (a.ta <= 0) {
+        a.ta = d0;
+        while (a.ta > 4 && (long)ceil_div(d0, a.ta) * a.nb * a.nc * a.nd * 2 * pairs < 2048) a.ta = (a.ta + 1) / 2;
+    }
+    a.ta = std::min(a.ta, d0);
+    a.na = ceil_div(d0, a.ta);
+    const size_t lds = nc_fused_lds_bytes(a.tb, a.tc, a.P);
+    P2P_REQUIRE(a.P <= 64 && lds <= 160 * 1024, P2P_EUNSUPPORTED, "consensus tile does not fit (P %d, LDS %zu)", a.P, lds);
+    int dev = 0;
+    P2P_HIP_CHECK(hipGetDevice(&dev));
+    static bool attr_set[64] = {false};
+    if (dev >= 64 || !attr_set[dev]) {
+        P2P_HIP_CHECK(hipFuncSetAttribute((const void *)nc_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (dev < 64) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(nc_fused_kernel, dim3(a.na * a.nb * a.nc * a.nd, 2, pairs), dim3(NCF_THREADS), lds, stream, a);
+    return check_launch("nc_fused_kernel");
+}
+
+}  // namespace p2p

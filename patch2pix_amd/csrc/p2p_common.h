@@ -75,6 +75,7 @@ struct p2p_ncn {
     float *b1cat;      // [32]
     float *w2m;        // [32][db][dc][da][dd]  layer-2: channels 0-15 direct branch, 16-31 transposed branch
     float b2;          // scalar bias of layer 2 (same for both branches)
+    unsigned char *wfused;   // both layers as fp16x2 MFMA fragments for the fused kernel (consensus.hip), own allocation
 };
 
 struct p2p_regressor {

@@ -151,6 +151,23 @@ def coarse_forward(feat_a, feat_b, ksize, ncn, want_delta=True, out_corr=None, o
     return corr[0], (delta[0] if delta is not None else None)
 
 
+def neigh_consensus_batch(x, ncn):
+    """NeighConsensus.forward (reference networks/ncn/model.py:145-155) on a batch of volumes x [B,hA,wA,hB,wB] fp32 GPU
+    -> the same shape: both consensus layers and both symmetric branches in one kernel (csrc/consensus.hip)."""
+    x = _f32c(x, "x")
+    if x.dim() != 5:
+        raise ValueError("neigh_consensus_batch expects [B,hA,wA,hB,wB]")
+    nb, ha, wa, hb, wb = x.shape
+    y = torch.empty_like(x)
+    if nb == 0 or x.numel() == 0:
+        return y
+    with torch.cuda.device(x.device):
+        ws = torch.empty(nb, dtype=torch.int32, device=x.device)
+        _lib.check(_lib.p2p_neigh_consensus_batch(x.data_ptr(), nb, ha, wa, hb, wb, ncn.handle, y.data_ptr(), ws.data_ptr(), nb * 4,
+                                                  _stream()), "p2p_neigh_consensus_batch")
+    return y
+
+
 def delta_unpack(delta, ksize):
     """Packed argmax byte -> the reference's (max_i, max_j, max_k, max_l) int64 tensors."""
     out = torch.empty((4,) + tuple(delta.shape), dtype=torch.int64, device=delta.device)

@@ -57,6 +57,16 @@ def coarse_forward_batch(emu, ncn, fa, fb, ksize, ws_pairs=None):
     return corr, delta
 
 
+def neigh_consensus_batch(emu, ncn, x):
+    """x [B,hA,wA,hB,wB] fp32 CPU -> NeighConsensus.forward (the fused kernel)."""
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    nb, ha, wa, hb, wb = x.shape
+    ws = torch.zeros(nb, dtype=torch.int32)
+    check(emu, emu.p2p_neigh_consensus_batch(ptr(x), nb, ha, wa, hb, wb, ncn, ptr(y), ptr(ws), nb * 4, None), "p2p_neigh_consensus_batch")
+    return y
+
+
 def coarse_matches_batch(emu, corr, delta, ksize, upsample, center=True):
     nb, ha, wa, hb, wb = corr.shape
     n = ha * wa + hb * wb

@@ -72,6 +72,7 @@ template <class T> static inline hipError_t hipMalloc(T **p, size_t n) {
 }
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
     hipemu::launch((grid), (block), (lds), [=]() { kernel(__VA_ARGS__); })
 

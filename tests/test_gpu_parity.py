@@ -117,13 +117,30 @@ def test_coarse_vs_oracle(hw, ksize, dev, ops, cweights):
     assert torch.allclose(s.cpu(), rs, rtol=1e-5)
 
 
-@pytest.mark.parametrize("tile", ["2,4,2,2,128", "3,5,3,3,256", "4,6,2,4,128", "2,4,3,30,256", "5,10,2,1,256"])
+@pytest.mark.parametrize("dims", [(7, 9, 8, 13), (30, 40, 30, 40), (5, 3, 6, 70)])
+def test_fused_consensus_vs_oracle(dims, dev, ops, cweights):
+    """NeighConsensus.forward as its own operator (p2p_neigh_consensus_batch: both layers, both branches, one kernel on the
+    fp16 matrix cores) against the oracle (ncn/model.py:145-155): a volume no multiple of the tile, the volume of a 480x640
+    pair, a B row longer than one column tile; a second batch item with negative values far above 1 (rescaled inside)."""
+    sd, ncn = cweights[0], cweights[1]
+    g = torch.Generator().manual_seed(sum(dims))
+    x = torch.rand(2, *dims, generator=g)
+    x[1] = (x[1] - 0.5) * 300.0
+    y = ops.neigh_consensus_batch(x.to(dev), ncn).cpu()
+    o_ncn, _, _ = orc.split_params(sd)
+    for b in range(2):
+        ref = orc.neigh_consensus(x[b], o_ncn)
+        assert (y[b] - ref).abs().max() <= 3e-6 * ref.abs().max(), (dims, b)
+    assert torch.equal(ops.neigh_consensus_batch(x.to(dev), ncn).cpu(), y), "the fused consensus kernel is not deterministic"
+
+
+@pytest.mark.parametrize("tile", ["2,3,2", "4,6,6", "0,2,5", "3,4,3", "30,6,6"])
 def test_consensus_layer2_tilings(tile, dev, ops, cweights, monkeypatch):
-    """The second consensus layer marches along the first axis in chunks of `ta` slices; the tile is normally picked
-    from the volume and batch size.  Force several (tb,tc,tdr,ta,threads) shapes, including chunks that do not
-    divide the axis and d-tiles narrower than the volume, on a volume small enough for the oracle."""
+    """The fused consensus kernel marches along the first axis in chunks of `ta` slices over tiles of tb x tc cells; the
+    tile is normally picked from the volume and batch size.  Force several (ta,tb,tc) shapes (0 = pick ta), including
+    chunks that do not divide the axes, on a volume small enough for the oracle."""
     sd, ncn, _, _ = cweights
-    monkeypatch.setenv("P2P_NC2_TILE", tile)
+    monkeypatch.setenv("P2P_NCF_TILE", tile)
     H, W = 112, 176                                     # pooled volume 7 x 11 x 7 x 11
     p1, p2 = synthetic.make_correlated_pyramids(321, H, W)
     o_ncn, _, _ = orc.split_params(sd)

@@ -348,6 +348,23 @@ def test_match_tail_against_reference_semantics(emu):
     assert len(got[2][1]) == 300
 
 
+@pytest.mark.parametrize("dims", [(4, 6, 4, 6), (7, 9, 8, 13), (5, 3, 6, 70), (13, 14, 9, 11)])
+def test_fused_consensus_against_oracle(dims, emu, sd):
+    """p2p_neigh_consensus_batch (both consensus layers in one kernel on the fp16 matrix cores, csrc/consensus.hip) ==
+    NeighConsensus.forward (ncn/model.py:145-155) of the oracle: volumes that are no multiples of the tile, a B row longer
+    than one column tile (70 > 60), a batch of two."""
+    g = torch.Generator().manual_seed(sum(dims))
+    x = torch.rand(3, *dims, generator=g)
+    x[1] = x[1] * 0.01                                  # a volume far below the scale the fp16 planes are laid out for
+    x[2] = (x[2] - 0.5) * 300.0                         # ... and one far above it, with negative values (the kernel rescales by max |x|)
+    ncn = emu_lib.ncn_create(emu, sd)
+    y = emu_lib.neigh_consensus_batch(emu, ncn, x)
+    o_ncn, _, _ = orc.split_params(sd)
+    for b in range(3):
+        ref = orc.neigh_consensus(x[b], o_ncn)
+        assert (y[b] - ref).abs().max() <= 3e-6 * ref.abs().max(), (dims, b, float((y[b] - ref).abs().max()), float(ref.abs().max()))
+
+
 def test_correlation_modes_agree(tmp_path):
     """The three arithmetic modes of the correlation GEMM (fp16x2 planes, the default; bf16x3 planes; the exact fp32 MFMA
     behind P2P_CORR_MODE=f32) in separate processes (the mode is read once): same relocalisation argmaxes, same
@@ -376,3 +393,10 @@ torch.save((corr, delta, m, s), sys.argv[1])
         a = outs[mode]
         assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), mode
         assert torch.allclose(a[0], b[0], rtol=2e-4, atol=1e-9) and torch.allclose(a[3], b[3], rtol=1e-4), mode
+    # the two implementations of the consensus layers: the fused fp16 matrix-core kernel (default) and the two fp32 VALU
+    # kernels with the hidden volume in HBM (P2P_NC_MODE=valu)
+    f = str(tmp_path / "valu.pt")
+    subprocess.check_call([sys.executable, "-c", code, f], env=dict(os.environ, P2P_NC_MODE="valu"), cwd=root)
+    a, b = torch.load(f), outs["fp16x2"]
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert torch.allclose(a[0], b[0], rtol=2e-4, atol=1e-9) and torch.allclose(a[3], b[3], rtol=1e-4)
