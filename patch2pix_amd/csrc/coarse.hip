@@ -447,7 +447,9 @@ __global__ __launch_bounds__(256) void mm_apply_kernel(const float *X, int nA, i
         float m = fabsf(v);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-        if ((threadIdx.x & 63) == 0) atomicMax(amax + blockIdx.z * sKeys, __float_as_int(m));
+        // the word only grows: a (possibly stale) plain read first keeps nearly every wave off the atomic unit
+        int *dst = amax + blockIdx.z * sKeys;
+        if ((threadIdx.x & 63) == 0 && __float_as_int(m) > *(volatile int *)dst) atomicMax(dst, __float_as_int(m));
     }
 }
 
@@ -914,13 +916,15 @@ int launch_nc_fused(const float *X, float *Y, size_t stride, int pairs, int d0, 
                     float b2, const int *xmax, size_t xmax_stride, hipStream_t stream);
 int launch_absmax(const float *x, size_t n, size_t stride, int pairs, int *out, size_t out_stride, hipStream_t stream);
 
-// the two consensus layers: "fused" (default: one kernel on the fp16 matrix cores, consensus.hip) or "valu" (the two fp32
-// VALU kernels above with the hidden volume in HBM, P2P_NC_MODE=valu)
+// the two consensus layers inside p2p_coarse_forward: "valu" (default: the two fp32 VALU kernels above, hidden volume in
+// HBM) or "fused" (P2P_NC_MODE=fused: one kernel on the fp16 matrix cores with the hidden volume in LDS, consensus.hip --
+// 50x less HBM traffic, but at 480x640 it is latency-bound by its small per-strip phases and measured slower: 431 us per
+// pair against 221, profiles/r03_ablation_log.txt; p2p_neigh_consensus_batch always runs it)
 static bool nc_fused() {
     static int mode = -1;
     if (mode < 0) {
         const char *e = getenv("P2P_NC_MODE");
-        mode = (e && !strcmp(e, "valu")) ? 0 : 1;
+        mode = (e && !strcmp(e, "fused")) ? 1 : 0;
     }
     return mode == 1;
 }

@@ -55,6 +55,7 @@ struct NcFusedArgs {
     size_t xmax_stride;
 };
 
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ unsigned short nf2h(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
 __device__ __forceinline__ float nh2f(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
 #define NCF_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(nh8, (a)), __builtin_bit_cast(nh8, (b)), (c), 0, 0, 0)
@@ -79,20 +80,25 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     const int YROW = TC * P, YSLOT = TB * YROW;              // accumulators: [3 slots][TB][TC * P] floats
     unsigned char *Xs = sm;
     unsigned char *Hs = sm + 2 * XPLANE;
-    float *Ya = (float *)(Hs + 2 * HPLANE);
+    unsigned char *W2s = Hs + 2 * HPLANE;                    // layer-2 B fragments
+    float *Ya = (float *)(W2s + NCF_W2_BYTES);
     const size_t nB = (size_t)a.d2 * a.d3;
 
     // weights of this branch -> registers (they are the B operands of every MFMA of the kernel)
     const unsigned char *wb = a.w + (size_t)br * NCF_BRANCH_BYTES;
-    nf4 w1[7][2], w2[5][2];
+    nf4 w1[7][2];
 #pragma unroll
     for (int s = 0; s < 7; ++s)
 #pragma unroll
         for (int p = 0; p < 2; ++p) w1[s][p] = *(const nf4 *)(wb + ((s * 2 + p) * 64 + lane) * 16);
+    // (the 10 layer-2 fragments go to LDS: 40 more registers would not fit beside the prefetched input rows)
+    for (int i = tid; i < NCF_W2_BYTES / 16; i += NCF_THREADS) *(nf4 *)(W2s + i * 16) = *(const nf4 *)(wb + NCF_W1_BYTES + i * 16);
+    // (made opaque so that their loads are waited for HERE: a wait inside the strip loop would also drain the input rows
+    // prefetched for the next strip)
 #pragma unroll
-    for (int s = 0; s < 5; ++s)
+    for (int s = 0; s < 7; ++s)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) w2[s][p] = *(const nf4 *)(wb + NCF_W1_BYTES + ((s * 2 + p) * 64 + lane) * 16);
+        for (int p = 0; p < 2; ++p) P2P_OPAQUE_V4(w1[s][p]);
     const float *cf = (const float *)(wb + NCF_W1_BYTES + NCF_W2_BYTES);
     // The fp16 planes are laid out for |X| <= 1 (what MutualMatching makes of non-negative correlations).  A volume with
     // larger values (negative correlations can do that) is scaled down by the power of two 2^E that brings its largest
@@ -130,106 +136,164 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
         for (int i = tid; i < YSLOT; i += NCF_THREADS) slot[i] = 0.f;
     };
 
-    for (int ap = ap_first; ap <= ap_last; ++ap) {
-        for (int bp = bp_first; bp <= bp_last; ++bp) {
-            // ---------------- S1: the nine input planes around the strip, two fp16 planes of X * 2^12
-            for (int r = wave; r < 9 * XROWS; r += NCF_WAVES) {
-                const int pl9 = r / XROWS, xr = r - pl9 * XROWS;
-                const int ia = ap + pl9 / 3 - 1, ib = bp + pl9 % 3 - 1, ic = c0 - 2 + xr, id = dt0 - 2 + lane;
-                const bool ok = lane < P && ia >= 0 && ia < a.d0 && ib >= 0 && ib < a.d1 && ic >= 0 && ic < a.d2 && id >= 0 && id < a.d3;
-                const float v = ok ? X[((size_t)ia * a.d1 + ib) * nB + (size_t)ic * a.d3 + id] * xscale : 0.f;
-                if (lane < P) {
+    // The strips (a', b') in order, a' outer.  The input rows of the NEXT strip are fetched into registers while the current
+    // one is computed (their latency is a microsecond).  Row addresses are wave-uniform (scalar base + the lane's clamped
+    // column), everything that does not depend on the strip is worked out once, here.
+    constexpr int NCF_XJ = 3;                                // input rows per wave and plane: (TC + 4) / 4 <= 3
+    const int nbp = bp_last - bp_first + 1, nstrips = (ap_last - ap_first + 1) * nbp;
+    float xv[9 * NCF_XJ];
+    unsigned xok_lo = 0, xok_hi = 0;                         // bit (pl9 * 4 + j): that row of the fetched strip is inside the volume
+    const int vcol = clampi(dt0 - 2 + lane, 0, a.d3 - 1);    // the lane's input column, clamped into the row
+    const bool okd = lane < P && dt0 - 2 + lane >= 0 && dt0 - 2 + lane < a.d3;
+    auto fetch = [&](int strip) {
+        const int ap = ap_first + strip / nbp, bp = bp_first + strip % nbp;
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int pl9 = 0; pl9 < 9; ++pl9) {
+            const int ia = ap + pl9 / 3 - 1, ib = bp + pl9 % 3 - 1;
+            const bool okab = ia >= 0 && ia < a.d0 && ib >= 0 && ib < a.d1;
+            const float *plane = X + ((size_t)clampi(ia, 0, a.d0 - 1) * a.d1 + clampi(ib, 0, a.d1 - 1)) * nB;
+#pragma unroll
+            for (int j = 0; j < NCF_XJ; ++j) {
+                const int xr = wave + NCF_WAVES * j, ic = c0 - 2 + xr;
+                const bool ok = okab && xr < XROWS && ic >= 0 && ic < a.d2;
+                // unconditional load from a clamped address; the zero padding is selected when the value is USED (a load in a
+                // branch, or a select right behind it, is waited for on the spot: dozens of round trips one after the other)
+                xv[pl9 * NCF_XJ + j] = plane[(size_t)clampi(ic, 0, a.d2 - 1) * a.d3 + vcol];
+                const int bit = pl9 * NCF_XJ + j;
+                if (bit < 32) lo |= (unsigned)ok << bit; else hi |= (unsigned)ok << (bit - 32);
+            }
+        }
+        xok_lo = okd ? lo : 0u;
+        xok_hi = okd ? hi : 0u;
+    };
+
+    // layer 1: this wave's m-tiles (<= 2): store offsets, validity of the 16 accumulator rows of the lane
+    const int l31 = lane & 31, kb5 = lane >> 5, ch = lane & 15, par = (lane >> 4) & 1;
+    const int nt1 = (HROWS * P + 63) >> 6;
+    unsigned s2ok[2] = {0, 0}, s2st[2] = {0, 0};
+    int s2dst[2] = {0, 0}, s2qh[2] = {0, 0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = wave + NCF_WAVES * u, q0 = t * 64;
+        s2qh[u] = min(q0 + 2 * l31, HROWS * P - 2);           // rows past the strip repeat its last row (never stored)
+        const int fl0 = q0 + 8 * kb5 + par;                   // D: row i = (r & 3) + 8 (r >> 2) + 4 kb -> position q0 + 2 i + par
+        s2dst[u] = (ch >> 3) * HKH + (ch & 7) * 2 + 16 + fl0 * 16;     // + 16: position -1 is slot 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int fl = fl0 + 2 * (r & 3) + 16 * (r >> 2), rowh = fl / P, col = fl - rowh * P;
+            const int ic = c0 - 1 + rowh, id = dt0 + col - 1;
+            const bool st = t < nt1 && rowh < HROWS;
+            const bool ok = st && col <= TD + 1 && ic >= 0 && ic < a.d2 && id >= 0 && id < a.d3;
+            s2ok[u] |= (unsigned)ok << r;
+            s2st[u] |= (unsigned)st << r;
+        }
+    }
+    // layer 2: hidden offsets of the lane's K block per step
+    const int row16 = lane & 15, kb4 = lane >> 4;
+    int s3off[5];
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const int tap = min(2 * st + (kb4 >> 1), 8);          // tap 9 does not exist (zero weights)
+        s3off[st] = (kb4 & 1) * HKH + ((tap / 3) * P + tap % 3) * 16;      // hidden position + dc P + dd - 1, slot + 1
+    }
+    const int nt2 = (TC * P + 15) >> 4;
+
+    if (nstrips > 0) fetch(0);
+    for (int strip = 0; strip < nstrips; ++strip) {
+        const int ap = ap_first + strip / nbp, bp = bp_first + strip % nbp;
+        // ---------------- S1: the nine input planes around the strip -> two fp16 planes of X * 2^12 in LDS
+#pragma unroll
+        for (int pl9 = 0; pl9 < 9; ++pl9)
+#pragma unroll
+            for (int j = 0; j < NCF_XJ; ++j) {
+                const int xr = wave + NCF_WAVES * j, bit = pl9 * NCF_XJ + j;
+                if (xr < XROWS && lane < P) {
+                    const bool ok = (bit < 32) ? (xok_lo >> bit) & 1u : (xok_hi >> (bit - 32)) & 1u;
+                    const float v = ok ? xv[bit] * xscale : 0.f;
                     const unsigned short h0 = nf2h(v);
-                    unsigned char *dst = Xs + (r * P + lane) * 2;
+                    unsigned char *dst = Xs + ((pl9 * XROWS + xr) * P + lane) * 2;
                     *(unsigned short *)dst = h0;
                     *(unsigned short *)(dst + XPLANE) = nf2h(v - nh2f(h0));
                 }
             }
-            __syncthreads();
-            // ---------------- S2: layer 1 -> hidden planes
-            {
-                const int l31 = lane & 31, kb = lane >> 5, o = lane & 15, s = (lane >> 4) & 1;
-                const int nt1 = (HROWS * P + 63) >> 6;
-                for (int t = wave; t < nt1; t += NCF_WAVES) {
-                    const int q0 = t * 64;
-                    const int qh = min(q0 + 2 * l31, HROWS * P - 2);       // rows past the strip repeat its last row (never stored)
-                    f32x16 acc = {0};
+        __syncthreads();
+        if (strip + 1 < nstrips) fetch(strip + 1);
+        // ---------------- S2: layer 1 -> hidden planes
+#ifndef NCF_SKIP_S2                     // timing experiments (wrong results): NCF_SKIP_S2 / _S3 / _S2EPI drop one part
 #pragma unroll
-                    for (int sl = 0; sl < 7; ++sl) {
-                        // the lane's two tap groups of this slab: g = 4 * sl + 2 * kb + {0, 1}; group 27 does not exist (zero weights)
-                        const int g0 = 4 * sl + 2 * kb, g1 = min(g0 + 1, 26);
-                        const int off0 = ((g0 / 3) * XROWS + g0 % 3) * P + qh, off1 = ((g1 / 3) * XROWS + g1 % 3) * P + qh;
-                        nf4 av[2];
+        for (int u = 0; u < 2; ++u) {
+            if (wave + NCF_WAVES * u < nt1) {
+                const int qh = s2qh[u];
+                f32x16 acc = {0};
 #pragma unroll
-                        for (int p = 0; p < 2; ++p) {
-                            const unsigned *x0 = (const unsigned *)(Xs + p * XPLANE + off0 * 2);
-                            const unsigned *x1 = (const unsigned *)(Xs + p * XPLANE + off1 * 2);
-                            av[p] = (nf4){__uint_as_float(x0[0]), __uint_as_float(x0[1]), __uint_as_float(x1[0]), __uint_as_float(x1[1])};
-                        }
-                        acc = NCF_MFMA32(av[1], w1[sl][0], acc);
-                        acc = NCF_MFMA32(av[0], w1[sl][1], acc);
-                        acc = NCF_MFMA32(av[0], w1[sl][0], acc);
+                for (int sl = 0; sl < 7; ++sl) {
+                    // the lane's two tap groups of this slab: g = 4 * sl + 2 * kb + {0, 1}; group 27 does not exist (zero weights)
+                    const int g0 = 4 * sl + 2 * kb5, g1 = min(g0 + 1, 26);
+                    const int off0 = ((g0 / 3) * XROWS + g0 % 3) * P + qh, off1 = ((g1 / 3) * XROWS + g1 % 3) * P + qh;
+                    nf4 av[2];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const unsigned *x0 = (const unsigned *)(Xs + p * XPLANE + off0 * 2);
+                        const unsigned *x1 = (const unsigned *)(Xs + p * XPLANE + off1 * 2);
+                        av[p] = (nf4){__uint_as_float(x0[0]), __uint_as_float(x0[1]), __uint_as_float(x1[0]), __uint_as_float(x1[1])};
                     }
-                    // D: row i = (r & 3) + 8 (r >> 2) + 4 kb -> flat position q0 + 2 i + s, column n = (s, o)
-                    const int fl0 = q0 + 8 * kb + s;
-                    const int row0 = fl0 / P, col0 = fl0 - row0 * P;
-                    unsigned char *hdst = Hs + (o >> 3) * HKH + (o & 7) * 2 + 16;     // + 16: position -1 is slot 0
+                    acc = NCF_MFMA32(av[1], w1[sl][0], acc);
+                    acc = NCF_MFMA32(av[0], w1[sl][1], acc);
+                    acc = NCF_MFMA32(av[0], w1[sl][0], acc);
+                }
+#ifndef NCF_SKIP_S2EPI
+                unsigned char *hdst = Hs + s2dst[u];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int off = 2 * (r & 3) + 16 * (r >> 2);
-                        // (a tile of 64 positions spans at most three rows when P >= 28; tiny volumes divide)
-                        const int tcol = col0 + off;
-                        const int wrap = (P >= 28) ? (tcol >= P) + (tcol >= 2 * P) : tcol / P;
-                        const int col = tcol - wrap * P, rowh = row0 + wrap;
-                        const int ic = c0 - 1 + rowh, id = dt0 + col - 1;
-                        const bool ok = rowh < HROWS && col <= TD + 1 && ic >= 0 && ic < a.d2 && id >= 0 && id < a.d3;
-                        const float h = ok ? fmaxf(fmaf(acc[r], s1o, b1o), 0.f) * hscale : 0.f;
-                        if (rowh < HROWS) {
-                            const unsigned short h0 = nf2h(h);
-                            unsigned char *d = hdst + (fl0 + off) * 16;
-                            *(unsigned short *)d = h0;
-                            *(unsigned short *)(d + HPLANE) = nf2h(h - nh2f(h0));
-                        }
+                for (int r = 0; r < 16; ++r) {
+                    const float h = ((s2ok[u] >> r) & 1u) ? fmaxf(fmaf(acc[r], s1o, b1o), 0.f) * hscale : 0.f;
+                    if ((s2st[u] >> r) & 1u) {
+                        const unsigned short h0 = nf2h(h);
+                        unsigned char *d = hdst + (2 * (r & 3) + 16 * (r >> 2)) * 16;
+                        *(unsigned short *)d = h0;
+                        *(unsigned short *)(d + HPLANE) = nf2h(h - nh2f(h0));
                     }
                 }
+#else
+                if (acc[0] == 12345.f) Hs[tid] = 1;
+#endif
             }
-            __syncthreads();
-            // ---------------- S3: layer 2, contributions of the strip to the 3 x 3 output planes around it
-            {
-                const int row = lane & 15, kb = lane >> 4, n = lane & 15;
-                const int da = n / 3, db = n - 3 * da;
-                const int aout = ap - da + 1, bout = bp - db + 1;
-                const bool lane_ok = n < 9 && aout >= a0 && aout < a_hi && bout >= b0 && bout < min(b0 + TB, a.d1);
-                float *ydst = Ya + ((aout + 3) % 3) * YSLOT + (bout - b0) * YROW;
-                const int nt2 = (TC * P + 15) >> 4;
-                for (int t = wave; t < nt2; t += NCF_WAVES) {
-                    const int q0 = t * 16;
-                    const int qo = min(q0 + row, TC * P - 1);
-                    nf4 acc = {0.f, 0.f, 0.f, 0.f};
+        }
+#endif
+        __syncthreads();
+        // ---------------- S3: layer 2, contributions of the strip to the 3 x 3 output planes around it
+#ifndef NCF_SKIP_S3
+        {
+            const int n = lane & 15, da = n / 3, db = n - 3 * da;
+            const int aout = ap - da + 1, bout = bp - db + 1;
+            const bool lane_ok = n < 9 && aout >= a0 && aout < a_hi && bout >= b0 && bout < min(b0 + TB, a.d1);
+            float *ydst = Ya + ((aout + 3) % 3) * YSLOT + (bout - b0) * YROW;
+            for (int t = wave; t < nt2; t += NCF_WAVES) {
+                const int q0 = t * 16;
+                const unsigned char *hq = Hs + min(q0 + row16, TC * P - 1) * 16;
+                nf4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int st = 0; st < 5; ++st) {
-                        const int tap = min(2 * st + (kb >> 1), 8);          // tap 9 does not exist (zero weights)
-                        const int dc = tap / 3, dd = tap - 3 * dc;
-                        const unsigned char *hp = Hs + (kb & 1) * HKH + (qo + dc * P + dd) * 16;   // hidden position qo + dc P + dd - 1, slot + 1
-                        const nf4 h0 = *(const nf4 *)hp, h1 = *(const nf4 *)(hp + HPLANE);
-                        acc = NCF_MFMA16(h1, w2[st][0], acc);
-                        acc = NCF_MFMA16(h0, w2[st][1], acc);
-                        acc = NCF_MFMA16(h0, w2[st][0], acc);
-                    }
-                    // D: row 4 kb + r = output position q0 + 4 kb + r, column n = plane (da, db)
-                    if (lane_ok) {
+                for (int st = 0; st < 5; ++st) {
+                    const nf4 h0 = *(const nf4 *)(hq + s3off[st]), h1 = *(const nf4 *)(hq + s3off[st] + HPLANE);
+                    const nf4 wa = *(const nf4 *)(W2s + ((st * 2) * 64 + lane) * 16), wbb = *(const nf4 *)(W2s + ((st * 2 + 1) * 64 + lane) * 16);
+                    acc = NCF_MFMA16(h1, wa, acc);
+                    acc = NCF_MFMA16(h0, wbb, acc);
+                    acc = NCF_MFMA16(h0, wa, acc);
+                }
+                // D: row 4 kb + r = output position q0 + 4 kb + r, column n = plane (da, db)
+                if (lane_ok) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int q = q0 + 4 * kb + r;
-                            if (q < TC * P) unsafeAtomicAdd(ydst + q, acc[r] * yun);
-                        }
+                    for (int r = 0; r < 4; ++r) {
+                        const int q = q0 + 4 * kb4 + r;
+                        if (q < TC * P) unsafeAtomicAdd(ydst + q, acc[r] * yun);
                     }
                 }
             }
         }
-        if (ap - 1 >= a0) flush(ap - 1);
+#endif
+        if (bp == bp_last && ap - 1 >= a0) flush(ap - 1);
     }
-    if (ap_last < a_hi && ap_last >= a0) flush(ap_last);      // the volume ends inside the tile: its last slice has no slice above
+    if (nstrips > 0 && ap_last < a_hi && ap_last >= a0) flush(ap_last);      // the volume ends inside the tile: its last slice has no slice above
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------
@@ -302,7 +366,7 @@ void pack_nc_fused(const float *w1, const float *b1, const float *w2, std::vecto
 }
 
 size_t nc_fused_lds_bytes(int tb, int tc, int P) {
-    return (size_t)2 * ((9 * (tc + 4) * P * 2 + 8 + 15) & ~15) + (size_t)2 * 2 * ((tc + 2) * P + 2) * 16 + (size_t)3 * tb * tc * P * 4;
+    return (size_t)2 * ((9 * (tc + 4) * P * 2 + 8 + 15) & ~15) + (size_t)2 * 2 * ((tc + 2) * P + 2) * 16 + (size_t)3 * tb * tc * P * 4 + NCF_W2_BYTES;
 }
 
 // float bits of max |x| over n values per pair -> out[pair * out_stride] (zero beforehand); one atomic per wave
@@ -312,7 +376,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-    if ((threadIdx.x & 63) == 0) atomicMax(out + (size_t)blockIdx.z * out_stride, __float_as_int(m));
+    int *dst = out + (size_t)blockIdx.z * out_stride;
+    if ((threadIdx.x & 63) == 0 && __float_as_int(m) > *(volatile int *)dst) atomicMax(dst, __float_as_int(m));
 }
 
 int launch_absmax(const float *x, size_t n, size_t stride, int pairs, int *out, size_t out_stride, hipStream_t stream) {
@@ -344,8 +409,11 @@ int launch_nc_fused(const float *X, float *Y, size_t stride, int pairs, int d0, 
     }
     a.ta = std::min(a.ta, d0);
     a.na = ceil_div(d0, a.ta);
+    // kernel limits: a row of <= 64 columns per wave instruction, <= 3 input rows per wave and plane, <= 2 layer-1 tiles per wave
+    while (a.tc > 1 && (a.tc + 4 > 12 || (a.tc + 2) * a.P > 512)) { --a.tc; a.nc = ceil_div(d2, a.tc); }
     const size_t lds = nc_fused_lds_bytes(a.tb, a.tc, a.P);
-    P2P_REQUIRE(a.P <= 64 && lds <= 160 * 1024, P2P_EUNSUPPORTED, "consensus tile does not fit (P %d, LDS %zu)", a.P, lds);
+    P2P_REQUIRE(a.P <= 64 && lds <= 160 * 1024 && a.tc + 4 <= 12 && (a.tc + 2) * a.P <= 512, P2P_EUNSUPPORTED,
+                "consensus tile does not fit (P %d, tc %d, LDS %zu)", a.P, a.tc, lds);
     int dev = 0;
     P2P_HIP_CHECK(hipGetDevice(&dev));
     static bool attr_set[64] = {false};

@@ -40,6 +40,9 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 #ifndef P2P_OPAQUE_S               // the same for a wave-uniform value in SGPRs (keeps an address computation on the scalar unit)
 #define P2P_OPAQUE_S(v) asm volatile("" : "+s"(v))
 #endif
+#ifndef P2P_OPAQUE_V4              // the same for a 16-byte vector value (four VGPRs)
+#define P2P_OPAQUE_V4(v) asm volatile("" : "+v"(v))
+#endif
 #ifndef P2P_LANE_ID                // lane index inside the wave, recomputed from the hardware (v_mbcnt) instead of kept in a register
 #define P2P_LANE_ID() ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
 #endif

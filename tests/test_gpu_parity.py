@@ -135,12 +135,25 @@ def test_fused_consensus_vs_oracle(dims, dev, ops, cweights):
 
 
 @pytest.mark.parametrize("tile", ["2,3,2", "4,6,6", "0,2,5", "3,4,3", "30,6,6"])
-def test_consensus_layer2_tilings(tile, dev, ops, cweights, monkeypatch):
+def test_fused_consensus_tilings(tile, dev, ops, cweights, monkeypatch):
     """The fused consensus kernel marches along the first axis in chunks of `ta` slices over tiles of tb x tc cells; the
     tile is normally picked from the volume and batch size.  Force several (ta,tb,tc) shapes (0 = pick ta), including
-    chunks that do not divide the axes, on a volume small enough for the oracle."""
-    sd, ncn, _, _ = cweights
+    chunks that do not divide the axes."""
+    sd, ncn = cweights[0], cweights[1]
     monkeypatch.setenv("P2P_NCF_TILE", tile)
+    x = torch.rand(1, 7, 11, 7, 11, generator=torch.Generator().manual_seed(5))
+    o_ncn, _, _ = orc.split_params(sd)
+    ref = orc.neigh_consensus(x[0], o_ncn)
+    assert (ops.neigh_consensus_batch(x.to(dev), ncn).cpu()[0] - ref).abs().max() <= 3e-6 * ref.abs().max()
+
+
+@pytest.mark.parametrize("tile", ["2,4,2,2,128", "3,5,3,3,256", "4,6,2,4,128", "2,4,3,30,256", "5,10,2,1,256"])
+def test_consensus_layer2_tilings(tile, dev, ops, cweights, monkeypatch):
+    """The second consensus layer marches along the first axis in chunks of `ta` slices; the tile is normally picked
+    from the volume and batch size.  Force several (tb,tc,tdr,ta,threads) shapes, including chunks that do not
+    divide the axis and d-tiles narrower than the volume, on a volume small enough for the oracle."""
+    sd, ncn, _, _ = cweights
+    monkeypatch.setenv("P2P_NC2_TILE", tile)
     H, W = 112, 176                                     # pooled volume 7 x 11 x 7 x 11
     p1, p2 = synthetic.make_correlated_pyramids(321, H, W)
     o_ncn, _, _ = orc.split_params(sd)

@@ -393,10 +393,10 @@ torch.save((corr, delta, m, s), sys.argv[1])
         a = outs[mode]
         assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), mode
         assert torch.allclose(a[0], b[0], rtol=2e-4, atol=1e-9) and torch.allclose(a[3], b[3], rtol=1e-4), mode
-    # the two implementations of the consensus layers: the fused fp16 matrix-core kernel (default) and the two fp32 VALU
-    # kernels with the hidden volume in HBM (P2P_NC_MODE=valu)
-    f = str(tmp_path / "valu.pt")
-    subprocess.check_call([sys.executable, "-c", code, f], env=dict(os.environ, P2P_NC_MODE="valu"), cwd=root)
+    # the two implementations of the consensus layers: the two fp32 VALU kernels with the hidden volume in HBM (default) and
+    # the fused fp16 matrix-core kernel (P2P_NC_MODE=fused)
+    f = str(tmp_path / "fused.pt")
+    subprocess.check_call([sys.executable, "-c", code, f], env=dict(os.environ, P2P_NC_MODE="fused"), cwd=root)
     a, b = torch.load(f), outs["fp16x2"]
     assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     assert torch.allclose(a[0], b[0], rtol=2e-4, atol=1e-9) and torch.allclose(a[3], b[3], rtol=1e-4)
