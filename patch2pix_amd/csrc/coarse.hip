@@ -916,17 +916,19 @@ int launch_nc_fused(const float *X, float *Y, size_t stride, int pairs, int d0, 
                     float b2, const int *xmax, size_t xmax_stride, hipStream_t stream);
 int launch_absmax(const float *x, size_t n, size_t stride, int pairs, int *out, size_t out_stride, hipStream_t stream);
 
-// the two consensus layers inside p2p_coarse_forward: "valu" (default: the two fp32 VALU kernels above, hidden volume in
-// HBM) or "fused" (P2P_NC_MODE=fused: one kernel on the fp16 matrix cores with the hidden volume in LDS, consensus.hip --
-// 50x less HBM traffic, but at 480x640 it is latency-bound by its small per-strip phases and measured slower: 431 us per
-// pair against 221, profiles/r03_ablation_log.txt; p2p_neigh_consensus_batch always runs it)
-static bool nc_fused() {
+bool nc_fused_fills_chip(int pairs, int d0, int d1, int d2, int d3);
+
+// The two consensus layers inside p2p_coarse_forward: the fused kernel on the fp16 matrix cores (consensus.hip: hidden volume
+// in LDS, 50x less HBM traffic) when the launch has enough work-groups to fill the chip -- batches of 480x640 pairs, any
+// 960x1280 pair --, otherwise the two fp32 VALU kernels above with the hidden volume in HBM (a single 480x640 pair: 0.48 ms
+// against 0.74 ms).  P2P_NC_MODE=fused / valu forces one of them.  Measurements: profiles/r03_ablation_log.txt.
+static bool nc_fused(int pairs, int d0, int d1, int d2, int d3) {
     static int mode = -1;
     if (mode < 0) {
         const char *e = getenv("P2P_NC_MODE");
-        mode = (e && !strcmp(e, "fused")) ? 1 : 0;
+        mode = (e && !strcmp(e, "fused")) ? 1 : (e && !strcmp(e, "valu")) ? 0 : 2;
     }
-    return mode == 1;
+    return mode == 2 ? nc_fused_fills_chip(pairs, d0, d1, d2, d3) : mode == 1;
 }
 
 }  // namespace p2p
@@ -1079,7 +1081,7 @@ extern "C" int p2p_coarse_forward_batch(const float *featA, const float *featB, 
         // first mutual matching, in place on the pooled volume (also clears Y for layer 2's atomic adds)
         hipLaunchKernelGGL(mm_apply_kernel, dim3((unsigned)((nel + 255) / 256), 1, nz), dim3(256), 0, stream, P, nAc, nBc, rkey1,
                            ckey1, P, sWs, sWs, sWs, Y, xmax);
-        if (nc_fused()) {
+        if (nc_fused((int)nz, v.d0, v.d1, v.d2, v.d3)) {
             const int st = launch_nc_fused(P, Y, sWs, (int)nz, v.d0, v.d1, v.d2, v.d3, ncn->wfused, ncn->b2, xmax, sWs, stream);
             if (st != P2P_OK) return st;
         } else {

@@ -73,7 +73,8 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     const int b0 = (g % a.nb) * a.tb; g /= a.nb;
     const int a0 = g * a.ta;
     const int TA = a.ta, TB = a.tb, TC = a.tc, TD = a.td, P = a.P;
-    const int XROWS = TC + 4, HROWS = TC + 2, HN = HROWS * P + 2;
+    const int XROWS = TC + 4, HROWS = TC + 2;
+    const int HN = max(HROWS * P, ((HROWS * P + 63) >> 6) * 64) + 2;      // whole layer-1 tiles fit (their tail rows store zeros)
     const int XPLANE = (9 * XROWS * P * 2 + 8 + 15) & ~15;   // bytes of one fp16 plane of the staged input (+ the window overrun of its
                                                              // last position; the hidden planes behind it need 16-byte alignment)
     const int HKH = HN * 16, HPLANE = 2 * HKH;               // hidden: [plane][channel half][position][8 x fp16]
@@ -143,25 +144,42 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     const int nbp = bp_last - bp_first + 1, nstrips = (ap_last - ap_first + 1) * nbp;
     float xv[9 * NCF_XJ];
     unsigned xok_lo = 0, xok_hi = 0;                         // bit (pl9 * 4 + j): that row of the fetched strip is inside the volume
-    const int vcol = clampi(dt0 - 2 + lane, 0, a.d3 - 1);    // the lane's input column, clamped into the row
     const bool okd = lane < P && dt0 - 2 + lane >= 0 && dt0 - 2 + lane < a.d3;
+    // 32-bit element offsets (a volume has < 2^31 cells): row part = clamped c row * d3 + the lane's clamped column (does
+    // not depend on the strip), plane part = clamped (a, b) * strides (three values each per strip, scalar)
+    const int sB = (int)nB, sA = a.d1 * sB;
+    int rowoff[NCF_XJ];
+    unsigned okc = 0;
+#pragma unroll
+    for (int j = 0; j < NCF_XJ; ++j) {
+        const int xr = wave + NCF_WAVES * j, ic = c0 - 2 + xr;
+        rowoff[j] = clampi(ic, 0, a.d2 - 1) * a.d3 + clampi(dt0 - 2 + lane, 0, a.d3 - 1);
+        okc |= (unsigned)(xr < XROWS && ic >= 0 && ic < a.d2) << j;
+    }
     auto fetch = [&](int strip) {
         const int ap = ap_first + strip / nbp, bp = bp_first + strip % nbp;
+        int pa[3], pb[3];
+        unsigned oka = 0, okb = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            pa[i] = clampi(ap + i - 1, 0, a.d0 - 1) * sA;
+            pb[i] = clampi(bp + i - 1, 0, a.d1 - 1) * sB;
+            oka |= (unsigned)(ap + i - 1 >= 0 && ap + i - 1 < a.d0) << i;
+            okb |= (unsigned)(bp + i - 1 >= 0 && bp + i - 1 < a.d1) << i;
+        }
         unsigned lo = 0, hi = 0;
 #pragma unroll
         for (int pl9 = 0; pl9 < 9; ++pl9) {
-            const int ia = ap + pl9 / 3 - 1, ib = bp + pl9 % 3 - 1;
-            const bool okab = ia >= 0 && ia < a.d0 && ib >= 0 && ib < a.d1;
-            const float *plane = X + ((size_t)clampi(ia, 0, a.d0 - 1) * a.d1 + clampi(ib, 0, a.d1 - 1)) * nB;
+            const int base = pa[pl9 / 3] + pb[pl9 % 3];
+            const unsigned okab = (oka >> (pl9 / 3)) & (okb >> (pl9 % 3)) & 1u;
 #pragma unroll
             for (int j = 0; j < NCF_XJ; ++j) {
-                const int xr = wave + NCF_WAVES * j, ic = c0 - 2 + xr;
-                const bool ok = okab && xr < XROWS && ic >= 0 && ic < a.d2;
                 // unconditional load from a clamped address; the zero padding is selected when the value is USED (a load in a
                 // branch, or a select right behind it, is waited for on the spot: dozens of round trips one after the other)
-                xv[pl9 * NCF_XJ + j] = plane[(size_t)clampi(ic, 0, a.d2 - 1) * a.d3 + vcol];
+                xv[pl9 * NCF_XJ + j] = X[base + rowoff[j]];
                 const int bit = pl9 * NCF_XJ + j;
-                if (bit < 32) lo |= (unsigned)ok << bit; else hi |= (unsigned)ok << (bit - 32);
+                const unsigned ok = okab & (okc >> j);
+                if (bit < 32) lo |= ok << bit; else hi |= ok << (bit - 32);
             }
         }
         xok_lo = okd ? lo : 0u;
@@ -171,7 +189,7 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     // layer 1: this wave's m-tiles (<= 2): store offsets, validity of the 16 accumulator rows of the lane
     const int l31 = lane & 31, kb5 = lane >> 5, ch = lane & 15, par = (lane >> 4) & 1;
     const int nt1 = (HROWS * P + 63) >> 6;
-    unsigned s2ok[2] = {0, 0}, s2st[2] = {0, 0};
+    unsigned s2ok[2] = {0, 0};
     int s2dst[2] = {0, 0}, s2qh[2] = {0, 0};
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -183,10 +201,8 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
         for (int r = 0; r < 16; ++r) {
             const int fl = fl0 + 2 * (r & 3) + 16 * (r >> 2), rowh = fl / P, col = fl - rowh * P;
             const int ic = c0 - 1 + rowh, id = dt0 + col - 1;
-            const bool st = t < nt1 && rowh < HROWS;
-            const bool ok = st && col <= TD + 1 && ic >= 0 && ic < a.d2 && id >= 0 && id < a.d3;
+            const bool ok = t < nt1 && rowh < HROWS && col <= TD + 1 && ic >= 0 && ic < a.d2 && id >= 0 && id < a.d3;
             s2ok[u] |= (unsigned)ok << r;
-            s2st[u] |= (unsigned)st << r;
         }
     }
     // layer 2: hidden offsets of the lane's K block per step
@@ -208,56 +224,65 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
 #pragma unroll
             for (int j = 0; j < NCF_XJ; ++j) {
                 const int xr = wave + NCF_WAVES * j, bit = pl9 * NCF_XJ + j;
-                if (xr < XROWS && lane < P) {
-                    const bool ok = (bit < 32) ? (xok_lo >> bit) & 1u : (xok_hi >> (bit - 32)) & 1u;
-                    const float v = ok ? xv[bit] * xscale : 0.f;
-                    const unsigned short h0 = nf2h(v);
-                    unsigned char *dst = Xs + ((pl9 * XROWS + xr) * P + lane) * 2;
-                    *(unsigned short *)dst = h0;
-                    *(unsigned short *)(dst + XPLANE) = nf2h(v - nh2f(h0));
-                }
+                const bool okv = (bit < 32) ? (xok_lo >> bit) & 1u : (xok_hi >> (bit - 32)) & 1u;
+                const float v = okv ? xv[bit] * xscale : 0.f;
+                const unsigned short h0 = nf2h(v), h1 = nf2h(v - nh2f(h0));
+                // columns (c, c + 1) sit in adjacent lanes: the even lane stores the pair's first plane, the odd lane its second
+                const bool oddl = lane & 1;
+                const unsigned mine = oddl ? h1 : h0, give = oddl ? h0 : h1;
+                const unsigned got = P2P_SWAP_ADJACENT(give);
+                if (xr < XROWS && lane < P)
+                    *(unsigned *)(Xs + (oddl ? XPLANE : 0) + ((pl9 * XROWS + xr) * P + (lane & ~1)) * 2) = oddl ? (got | mine << 16) : (mine | got << 16);
             }
         __syncthreads();
         if (strip + 1 < nstrips) fetch(strip + 1);
         // ---------------- S2: layer 1 -> hidden planes
 #ifndef NCF_SKIP_S2                     // timing experiments (wrong results): NCF_SKIP_S2 / _S3 / _S2EPI drop one part
+        {
+            // both m-tiles of the wave together (independent accumulators, the weights are shared); a wave with one tile
+            // multiplies a clamped copy of it -- it would wait at the barrier for the others anyway
+            f32x16 acc[2] = {{0}, {0}};
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (wave + NCF_WAVES * u < nt1) {
-                const int qh = s2qh[u];
-                f32x16 acc = {0};
+            for (int sl = 0; sl < 7; ++sl) {
+                // the lane's two tap groups of this slab: g = 4 * sl + 2 * kb + {0, 1}; group 27 does not exist (zero weights)
+                const int g0 = 4 * sl + 2 * kb5, g1 = min(g0 + 1, 26);
+                const int o0 = ((g0 / 3) * XROWS + g0 % 3) * P, o1 = ((g1 / 3) * XROWS + g1 % 3) * P;
+                nf4 av[2][2];
 #pragma unroll
-                for (int sl = 0; sl < 7; ++sl) {
-                    // the lane's two tap groups of this slab: g = 4 * sl + 2 * kb + {0, 1}; group 27 does not exist (zero weights)
-                    const int g0 = 4 * sl + 2 * kb5, g1 = min(g0 + 1, 26);
-                    const int off0 = ((g0 / 3) * XROWS + g0 % 3) * P + qh, off1 = ((g1 / 3) * XROWS + g1 % 3) * P + qh;
-                    nf4 av[2];
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int p = 0; p < 2; ++p) {
-                        const unsigned *x0 = (const unsigned *)(Xs + p * XPLANE + off0 * 2);
-                        const unsigned *x1 = (const unsigned *)(Xs + p * XPLANE + off1 * 2);
-                        av[p] = (nf4){__uint_as_float(x0[0]), __uint_as_float(x0[1]), __uint_as_float(x1[0]), __uint_as_float(x1[1])};
+                        const unsigned *x0 = (const unsigned *)(Xs + p * XPLANE + (o0 + s2qh[u]) * 2);
+                        const unsigned *x1 = (const unsigned *)(Xs + p * XPLANE + (o1 + s2qh[u]) * 2);
+                        av[u][p] = (nf4){__uint_as_float(x0[0]), __uint_as_float(x0[1]), __uint_as_float(x1[0]), __uint_as_float(x1[1])};
                     }
-                    acc = NCF_MFMA32(av[1], w1[sl][0], acc);
-                    acc = NCF_MFMA32(av[0], w1[sl][1], acc);
-                    acc = NCF_MFMA32(av[0], w1[sl][0], acc);
-                }
+                acc[0] = NCF_MFMA32(av[0][1], w1[sl][0], acc[0]); acc[1] = NCF_MFMA32(av[1][1], w1[sl][0], acc[1]);
+                acc[0] = NCF_MFMA32(av[0][0], w1[sl][1], acc[0]); acc[1] = NCF_MFMA32(av[1][0], w1[sl][1], acc[1]);
+                acc[0] = NCF_MFMA32(av[0][0], w1[sl][0], acc[0]); acc[1] = NCF_MFMA32(av[1][0], w1[sl][0], acc[1]);
+            }
 #ifndef NCF_SKIP_S2EPI
-                unsigned char *hdst = Hs + s2dst[u];
+            // bias, ReLU, zero outside the volume, scale, split.  Channel pairs (o, o + 1) sit in adjacent lanes: the even lane
+            // stores the pair's first plane, the odd lane its second plane -- one 4-byte store per lane and row instead of two
+            // 2-byte ones
+            const bool odd = ch & 1;
+            const float s1h = s1o * hscale, b1h = b1o * hscale;      // relu(x) * 2^k = relu(x * 2^k)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (wave + NCF_WAVES * u >= nt1) break;               // (wave-uniform) the clamped copy is not stored
+                unsigned char *hdst = Hs + s2dst[u] + (odd ? HPLANE - 2 : 0);      // the pair's first channel in this lane's plane
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float h = ((s2ok[u] >> r) & 1u) ? fmaxf(fmaf(acc[r], s1o, b1o), 0.f) * hscale : 0.f;
-                    if ((s2st[u] >> r) & 1u) {
-                        const unsigned short h0 = nf2h(h);
-                        unsigned char *d = hdst + (2 * (r & 3) + 16 * (r >> 2)) * 16;
-                        *(unsigned short *)d = h0;
-                        *(unsigned short *)(d + HPLANE) = nf2h(h - nh2f(h0));
-                    }
+                    const float h = ((s2ok[u] >> r) & 1u) ? fmaxf(fmaf(acc[u][r], s1h, b1h), 0.f) : 0.f;
+                    const unsigned short h0 = nf2h(h), h1 = nf2h(h - nh2f(h0));
+                    const unsigned mine = odd ? h1 : h0, give = odd ? h0 : h1;       // keep the half of my plane, hand the other to the partner
+                    const unsigned got = P2P_SWAP_ADJACENT(give);
+                    const unsigned word = odd ? (got | mine << 16) : (mine | got << 16);
+                    *(unsigned *)(hdst + (2 * (r & 3) + 16 * (r >> 2)) * 16) = word;
                 }
-#else
-                if (acc[0] == 12345.f) Hs[tid] = 1;
-#endif
             }
+#else
+            if (acc[0][0] == 12345.f || acc[1][0] == 12345.f) Hs[tid] = 1;
+#endif
         }
 #endif
         __syncthreads();
@@ -268,24 +293,57 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
             const int aout = ap - da + 1, bout = bp - db + 1;
             const bool lane_ok = n < 9 && aout >= a0 && aout < a_hi && bout >= b0 && bout < min(b0 + TB, a.d1);
             float *ydst = Ya + ((aout + 3) % 3) * YSLOT + (bout - b0) * YROW;
-            for (int t = wave; t < nt2; t += NCF_WAVES) {
-                const int q0 = t * 16;
-                const unsigned char *hq = Hs + min(q0 + row16, TC * P - 1) * 16;
-                nf4 acc = {0.f, 0.f, 0.f, 0.f};
+            // two m-tiles at a time (independent accumulators), the fragments of step st + 1 in flight during the MFMAs of step st
+            const bool yalign = (YROW & 3) == 0;               // every (slot, plane) row of the accumulators starts 16-byte aligned
+            for (int t = wave; t < nt2; t += 2 * NCF_WAVES) {
+                const int qa = t * 16, qb = qa + NCF_WAVES * 16;
+                const unsigned char *ha = Hs + min(qa + row16, TC * P - 1) * 16, *hb = Hs + min(qb + row16, TC * P - 1) * 16;
+                const unsigned char *wl = W2s + lane * 16;
+                nf4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+                nf4 a0v = *(const nf4 *)(ha + s3off[0]), a1v = *(const nf4 *)(ha + s3off[0] + HPLANE);
+                nf4 b0v = *(const nf4 *)(hb + s3off[0]), b1v = *(const nf4 *)(hb + s3off[0] + HPLANE);
+                nf4 w0v = *(const nf4 *)wl, w1v = *(const nf4 *)(wl + 1024);
 #pragma unroll
                 for (int st = 0; st < 5; ++st) {
-                    const nf4 h0 = *(const nf4 *)(hq + s3off[st]), h1 = *(const nf4 *)(hq + s3off[st] + HPLANE);
-                    const nf4 wa = *(const nf4 *)(W2s + ((st * 2) * 64 + lane) * 16), wbb = *(const nf4 *)(W2s + ((st * 2 + 1) * 64 + lane) * 16);
-                    acc = NCF_MFMA16(h1, wa, acc);
-                    acc = NCF_MFMA16(h0, wbb, acc);
-                    acc = NCF_MFMA16(h0, wa, acc);
+                    nf4 na0 = a0v, na1 = a1v, nb0 = b0v, nb1 = b1v, nw0 = w0v, nw1 = w1v;
+                    if (st < 4) {
+                        na0 = *(const nf4 *)(ha + s3off[st + 1]); na1 = *(const nf4 *)(ha + s3off[st + 1] + HPLANE);
+                        nb0 = *(const nf4 *)(hb + s3off[st + 1]); nb1 = *(const nf4 *)(hb + s3off[st + 1] + HPLANE);
+                        nw0 = *(const nf4 *)(wl + (st + 1) * 2048); nw1 = *(const nf4 *)(wl + (st + 1) * 2048 + 1024);
+                    }
+                    accA = NCF_MFMA16(a1v, w0v, accA); accB = NCF_MFMA16(b1v, w0v, accB);
+                    accA = NCF_MFMA16(a0v, w1v, accA); accB = NCF_MFMA16(b0v, w1v, accB);
+                    accA = NCF_MFMA16(a0v, w0v, accA); accB = NCF_MFMA16(b0v, w0v, accB);
+                    a0v = na0; a1v = na1; b0v = nb0; b1v = nb1; w0v = nw0; w1v = nw1;
                 }
-                // D: row 4 kb + r = output position q0 + 4 kb + r, column n = plane (da, db)
+                // D: row 4 kb + r = output position q + 4 kb + r, column n = plane (da, db).  Plain read-add-write: inside a
+                // strip every accumulator word is touched by exactly one lane (other tiles = other positions, other lanes =
+                // other planes or rows), strips are separated by barriers.  (ds_add_f32 cost ~600 cycles per wave instruction.)
                 if (lane_ok) {
+                    float *ya = ydst + qa + 4 * kb4, *yb = ydst + qb + 4 * kb4;
+                    if (yalign) {
+                        if (qa + 4 * kb4 + 3 < TC * P) {
+                            nf4 v = *(nf4 *)ya;
+                            v += accA * yun;
+                            *(nf4 *)ya = v;
+                        } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int q = q0 + 4 * kb4 + r;
-                        if (q < TC * P) unsafeAtomicAdd(ydst + q, acc[r] * yun);
+                            for (int r = 0; r < 4; ++r) if (qa + 4 * kb4 + r < TC * P) ya[r] += accA[r] * yun;
+                        }
+                        if (qb + 4 * kb4 + 3 < TC * P) {
+                            nf4 v = *(nf4 *)yb;
+                            v += accB * yun;
+                            *(nf4 *)yb = v;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) if (qb + 4 * kb4 + r < TC * P) yb[r] += accB[r] * yun;
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (qa + 4 * kb4 + r < TC * P) ya[r] += accA[r] * yun;
+                            if (qb + 4 * kb4 + r < TC * P) yb[r] += accB[r] * yun;
+                        }
                     }
                 }
             }
@@ -366,7 +424,7 @@ void pack_nc_fused(const float *w1, const float *b1, const float *w2, std::vecto
 }
 
 size_t nc_fused_lds_bytes(int tb, int tc, int P) {
-    return (size_t)2 * ((9 * (tc + 4) * P * 2 + 8 + 15) & ~15) + (size_t)2 * 2 * ((tc + 2) * P + 2) * 16 + (size_t)3 * tb * tc * P * 4 + NCF_W2_BYTES;
+    return (size_t)2 * ((9 * (tc + 4) * P * 2 + 8 + 15) & ~15) + (size_t)2 * 2 * (std::max((tc + 2) * P, (((tc + 2) * P + 63) >> 6) * 64) + 2) * 16 + (size_t)3 * tb * tc * P * 4 + 256 + NCF_W2_BYTES;
 }
 
 // float bits of max |x| over n values per pair -> out[pair * out_stride] (zero beforehand); one atomic per wave
@@ -386,31 +444,45 @@ int launch_absmax(const float *x, size_t n, size_t stride, int pairs, int *out, 
     return check_launch("absmax_kernel");
 }
 
+// Tile of the fused kernel for a volume and batch: the B row in pieces of <= 60 columns; (TB, TC) = (5, 8) keeps two
+// work-groups per compute unit (78 KB of LDS each) and gives 7 + 22 well-balanced MFMA tiles per strip; the march along a is
+// split only until the launch has >= 1024 work-groups (two per compute unit, twice over).  Returns the number of work-groups.
+static long nc_fused_tile(NcFusedArgs &a, int pairs) {
+    const int d0 = a.d0, d1 = a.d1, d2 = a.d2, d3 = a.d3;
+    a.nd = ceil_div(d3, 60);
+    a.td = ceil_div(d3, a.nd);
+    a.P = (a.td + 4 + 1) & ~1;
+    a.tb = 5; a.tc = 8; a.ta = 0;
+    if (const char *e = getenv("P2P_NCF_TILE")) {       // experiments: "ta,tb,tc" (ta = 0: pick)
+        int ta = 0, tb = 0, tc = 0;
+        if (sscanf(e, "%d,%d,%d", &ta, &tb, &tc) == 3 && tb > 0 && tc > 0) { a.tb = tb; a.tc = tc; a.ta = ta; }
+    }
+    a.tb = std::min(a.tb, d1); a.tc = std::min(a.tc, d2);
+    // kernel limits: a row of <= 64 columns per wave instruction, <= 3 input rows per wave and plane, <= 2 layer-1 tiles per wave
+    while (a.tc > 1 && (a.tc + 4 > 12 || (a.tc + 2) * a.P > 512)) --a.tc;
+    a.nb = ceil_div(d1, a.tb); a.nc = ceil_div(d2, a.tc);
+    if (a.ta <= 0) {
+        a.ta = d0;
+        while (a.ta > 4 && (long)ceil_div(d0, a.ta) * a.nb * a.nc * a.nd * 2 * pairs < 1024) a.ta = (a.ta + 1) / 2;
+    }
+    a.ta = std::min(a.ta, d0);
+    a.na = ceil_div(d0, a.ta);
+    return (long)a.na * a.nb * a.nc * a.nd * 2 * pairs;
+}
+
+// enough work-groups for the fused kernel to fill the chip?  (a single 480x640 pair is not: 128 work-groups of 4 waves)
+bool nc_fused_fills_chip(int pairs, int d0, int d1, int d2, int d3) {
+    NcFusedArgs a{};
+    a.d0 = d0; a.d1 = d1; a.d2 = d2; a.d3 = d3;
+    return nc_fused_tile(a, pairs) >= 1024;
+}
+
 int launch_nc_fused(const float *X, float *Y, size_t stride, int pairs, int d0, int d1, int d2, int d3, const unsigned char *w_dev,
                     float b2, const int *xmax, size_t xmax_stride, hipStream_t stream) {
     NcFusedArgs a{};
     a.X = X; a.Y = Y; a.stride = stride; a.d0 = d0; a.d1 = d1; a.d2 = d2; a.d3 = d3; a.w = w_dev; a.b2 = b2;
     a.xmax = xmax; a.xmax_stride = xmax_stride;
-    // tile: the B row in pieces of <= 60 columns; (TB, TC) as large as two work-groups per compute unit allow; TA splits the
-    // march until the launch has a few work-groups per compute unit
-    a.nd = ceil_div(d3, 60);
-    a.td = ceil_div(d3, a.nd);
-    a.P = (a.td + 4 + 1) & ~1;
-    a.tb = 6; a.tc = 6;
-    if (const char *e = getenv("P2P_NCF_TILE")) {       // experiments: "ta,tb,tc"
-        int ta = 0, tb = 0, tc = 0;
-        if (sscanf(e, "%d,%d,%d", &ta, &tb, &tc) == 3 && tb > 0 && tc > 0) { a.tb = tb; a.tc = tc; a.ta = ta; }
-    }
-    a.tb = std::min(a.tb, d1); a.tc = std::min(a.tc, d2);
-    a.nb = ceil_div(d1, a.tb); a.nc = ceil_div(d2, a.tc);
-    if (a.ta <= 0) {
-        a.ta = d0;
-        while (a.ta > 4 && (long)ceil_div(d0, a.ta) * a.nb * a.nc * a.nd * 2 * pairs < 2048) a.ta = (a.ta + 1) / 2;
-    }
-    a.ta = std::min(a.ta, d0);
-    a.na = ceil_div(d0, a.ta);
-    // kernel limits: a row of <= 64 columns per wave instruction, <= 3 input rows per wave and plane, <= 2 layer-1 tiles per wave
-    while (a.tc > 1 && (a.tc + 4 > 12 || (a.tc + 2) * a.P > 512)) { --a.tc; a.nc = ceil_div(d2, a.tc); }
+    nc_fused_tile(a, pairs);
     const size_t lds = nc_fused_lds_bytes(a.tb, a.tc, a.P);
     P2P_REQUIRE(a.P <= 64 && lds <= 160 * 1024 && a.tc + 4 <= 12 && (a.tc + 2) * a.P <= 512, P2P_EUNSUPPORTED,
                 "consensus tile does not fit (P %d, tc %d, LDS %zu)", a.P, a.tc, lds);
