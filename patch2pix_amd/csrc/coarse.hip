@@ -392,29 +392,42 @@ __global__ void fill_keys_kernel(int *p, int n, size_t sKeys) {
 }
 
 // column maxima: a thread owns one column over a 64-row chunk; chunks meet in an (order independent) atomicMax
+// (X2: optional second addend of every value -- the fused consensus kernel leaves its two branches in two arrays)
 __global__ __launch_bounds__(256) void colmax_kernel(const float *__restrict__ X, int nA, int nB, int *ckey, size_t sX,
-                                                     size_t sKeys) {
+                                                     size_t sKeys, const float *__restrict__ X2) {
     X += blockIdx.z * sX;
+    if (X2) X2 += blockIdx.z * sX;
     ckey += blockIdx.z * sKeys;
     const int col = blockIdx.x * 256 + threadIdx.x;
     if (col >= nB) return;
     const int r0 = blockIdx.y * 64, r1 = min(r0 + 64, nA);
     float cm = -INFINITY;
+    if (X2) {
 #pragma unroll 8
-    for (int r = r0; r < r1; ++r) cm = fmaxf(cm, X[(size_t)r * nB + col]);
+        for (int r = r0; r < r1; ++r) cm = fmaxf(cm, X[(size_t)r * nB + col] + X2[(size_t)r * nB + col]);
+    } else {
+#pragma unroll 8
+        for (int r = r0; r < r1; ++r) cm = fmaxf(cm, X[(size_t)r * nB + col]);
+    }
     atomicMax(&ckey[col], f2key(cm));
 }
 
 // row maxima: one wave per row
 __global__ __launch_bounds__(256) void rowmax_kernel(const float *__restrict__ X, int nA, int nB, int *rkey, size_t sX,
-                                                     size_t sKeys) {
+                                                     size_t sKeys, const float *__restrict__ X2) {
     X += blockIdx.z * sX;
+    if (X2) X2 += blockIdx.z * sX;
     rkey += blockIdx.z * sKeys;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= nA) return;
     const float *x = X + (size_t)row * nB;
     float rm = -INFINITY;
-    for (int c = lane; c < nB; c += 64) rm = fmaxf(rm, x[c]);
+    if (X2) {
+        const float *x2 = X2 + (size_t)row * nB;
+        for (int c = lane; c < nB; c += 64) rm = fmaxf(rm, x[c] + x2[c]);
+    } else {
+        for (int c = lane; c < nB; c += 64) rm = fmaxf(rm, x[c]);
+    }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) rm = fmaxf(rm, __shfl_xor(rm, m));
     if (lane == 0) rkey[row] = f2key(rm);
@@ -430,8 +443,9 @@ __device__ __forceinline__ float mm_value(float x, float max_over_b, float max_o
 // (in place when out == X)
 __global__ __launch_bounds__(256) void mm_apply_kernel(const float *X, int nA, int nB, const int *__restrict__ rkey,
                                                        const int *__restrict__ ckey, float *out, size_t sX, size_t sKeys,
-                                                       size_t sOut, float *__restrict__ zero, int *amax) {
+                                                       size_t sOut, float *__restrict__ zero, int *amax, const float *X2) {
     X += blockIdx.z * sX;
+    if (X2) X2 += blockIdx.z * sX;
     rkey += blockIdx.z * sKeys;
     ckey += blockIdx.z * sKeys;
     out += blockIdx.z * sOut;
@@ -439,7 +453,7 @@ __global__ __launch_bounds__(256) void mm_apply_kernel(const float *X, int nA, i
     float v = 0.f;
     if (i < (size_t)nA * nB) {
         const int r = (int)(i / nB), c = (int)(i - (size_t)r * nB);
-        v = mm_value(X[i], key2f(rkey[r]), key2f(ckey[c]));
+        v = mm_value(X2 ? X[i] + X2[i] : X[i], key2f(rkey[r]), key2f(ckey[c]));
         out[i] = v;
         if (zero) zero[blockIdx.z * sX + i] = 0.f;      // same index space: clears the accumulation target of the consensus layers
     }
@@ -912,8 +926,8 @@ static CoarseWs coarse_ws(int C, int hA, int wA, int hB, int wB, int k) {
 
 // consensus.hip
 void pack_nc_fused(const float *w1, const float *b1, const float *w2, std::vector<unsigned char> &out);
-int launch_nc_fused(const float *X, float *Y, size_t stride, int pairs, int d0, int d1, int d2, int d3, const unsigned char *w_dev,
-                    float b2, const int *xmax, size_t xmax_stride, hipStream_t stream);
+int launch_nc_fused(const float *X, float *Y, float *Y2, size_t stride, int pairs, int d0, int d1, int d2, int d3,
+                    const unsigned char *w_dev, float b2, const int *xmax, size_t xmax_stride, hipStream_t stream);
 int launch_absmax(const float *x, size_t n, size_t stride, int pairs, int *out, size_t out_stride, hipStream_t stream);
 
 bool nc_fused_fills_chip(int pairs, int d0, int d1, int d2, int d3);
@@ -1075,15 +1089,18 @@ extern "C" int p2p_coarse_forward_batch(const float *featA, const float *featB, 
         hipLaunchKernelGGL(fill_keys_kernel, dim3(ceil_div(nkeys + 1, 256), 1, nz), dim3(256), 0, stream, rkey1, nkeys, sWs);
         int *xmax = rkey1 + nkeys;
         const dim3 mgrid(ceil_div(nBc, 256), ceil_div(nAc, 64), nz);
-        hipLaunchKernelGGL(colmax_kernel, mgrid, dim3(256), 0, stream, P, nAc, nBc, ckey1, sWs, sWs);
-        hipLaunchKernelGGL(rowmax_kernel, dim3(ceil_div(nAc, 4), 1, nz), dim3(256), 0, stream, P, nAc, nBc, rkey1, sWs, sWs);
+        hipLaunchKernelGGL(colmax_kernel, mgrid, dim3(256), 0, stream, P, nAc, nBc, ckey1, sWs, sWs, (const float *)nullptr);
+        hipLaunchKernelGGL(rowmax_kernel, dim3(ceil_div(nAc, 4), 1, nz), dim3(256), 0, stream, P, nAc, nBc, rkey1, sWs, sWs, (const float *)nullptr);
 
         // first mutual matching, in place on the pooled volume (also clears Y for layer 2's atomic adds)
         hipLaunchKernelGGL(mm_apply_kernel, dim3((unsigned)((nel + 255) / 256), 1, nz), dim3(256), 0, stream, P, nAc, nBc, rkey1,
-                           ckey1, P, sWs, sWs, sWs, Y, xmax);
+                           ckey1, P, sWs, sWs, sWs, Y, xmax, (const float *)nullptr);
+        const float *Y2 = nullptr;          // second addend of the consensus output (fused kernel: the transposed branch)
         if (nc_fused((int)nz, v.d0, v.d1, v.d2, v.d3)) {
-            const int st = launch_nc_fused(P, Y, sWs, (int)nz, v.d0, v.d1, v.d2, v.d3, ncn->wfused, ncn->b2, xmax, sWs, stream);
+            // the branches write relu(.) with plain stores into Y and into the (otherwise unused) head of the H1 region
+            const int st = launch_nc_fused(P, Y, H1, sWs, (int)nz, v.d0, v.d1, v.d2, v.d3, ncn->wfused, ncn->b2, xmax, sWs, stream);
             if (st != P2P_OK) return st;
+            Y2 = H1;
         } else {
             const int ntiles = v.d0 * ceil_div(v.d1, L1_TB) * ceil_div(nBc, L1_Q);
             const size_t lds1 = (size_t)3 * (L1_TB + 2) * l1_rows(v.d3) * (v.d3 + 2) * 4;
@@ -1099,10 +1116,10 @@ extern "C" int p2p_coarse_forward_batch(const float *featA, const float *featB, 
                 hipLaunchKernelGGL(nc_layer2_kernel<false>, dim3(ntiles2, 2, nz), dim3(nt.nthreads), lds2, stream, H1, v, nt, ncn->w2m,
                                    ncn->b2, Y, sWs);
         }
-        hipLaunchKernelGGL(colmax_kernel, mgrid, dim3(256), 0, stream, Y, nAc, nBc, ckey2, sWs, sWs);
-        hipLaunchKernelGGL(rowmax_kernel, dim3(ceil_div(nAc, 4), 1, nz), dim3(256), 0, stream, Y, nAc, nBc, rkey2, sWs, sWs);
+        hipLaunchKernelGGL(colmax_kernel, mgrid, dim3(256), 0, stream, Y, nAc, nBc, ckey2, sWs, sWs, Y2);
+        hipLaunchKernelGGL(rowmax_kernel, dim3(ceil_div(nAc, 4), 1, nz), dim3(256), 0, stream, Y, nAc, nBc, rkey2, sWs, sWs, Y2);
         hipLaunchKernelGGL(mm_apply_kernel, dim3((unsigned)((nel + 255) / 256), 1, nz), dim3(256), 0, stream, Y, nAc, nBc, rkey2,
-                           ckey2, out, sWs, sWs, nel, (float *)nullptr, (int *)nullptr);
+                           ckey2, out, sWs, sWs, nel, (float *)nullptr, (int *)nullptr, Y2);
     }
     return check_launch("coarse_forward kernels");
 }
@@ -1127,7 +1144,7 @@ extern "C" int p2p_neigh_consensus_batch(const float *x, int batch, int hA, int 
     P2P_HIP_CHECK(hipMemsetAsync(xmax, 0, (size_t)batch * sizeof(int), stream));
     const int st = launch_absmax(x, nel, nel, batch, xmax, 1, stream);
     if (st != P2P_OK) return st;
-    return launch_nc_fused(x, y_out, nel, batch, hA, wA, hB, wB, ncn->wfused, ncn->b2, xmax, 1, stream);
+    return launch_nc_fused(x, y_out, nullptr, nel, batch, hA, wA, hB, wB, ncn->wfused, ncn->b2, xmax, 1, stream);
 }
 
 extern "C" int p2p_delta_unpack(const uint8_t *delta, size_t n, int ksize, int64_t *out, p2p_stream_t stream) {

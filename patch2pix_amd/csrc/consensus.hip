@@ -44,7 +44,8 @@ constexpr int NCF_BRANCH_BYTES = NCF_W1_BYTES + NCF_W2_BYTES + NCF_C_FLOATS * 4;
 
 struct NcFusedArgs {
     const float *X;          // [nA][nB] per pair
-    float *Y;                // [nA][nB] per pair, zero on entry
+    float *Y;                // [nA][nB] per pair; Y2 == null: zero on entry, both branches are ADDED to it (two addends per cell)
+    float *Y2;               // optional [nA][nB] per pair: the transposed branch is stored here, the direct one in Y (plain stores)
     size_t stride;           // floats between pairs (both arrays)
     int d0, d1, d2, d3;
     int ta, tb, tc, td, P;   // tile, flat pitch (even, >= td + 4, <= 64)
@@ -66,7 +67,8 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int br = blockIdx.y;
     const float *X = a.X + (size_t)blockIdx.z * a.stride;
-    float *Y = a.Y + (size_t)blockIdx.z * a.stride;
+    float *Y = ((br && a.Y2) ? a.Y2 : a.Y) + (size_t)blockIdx.z * a.stride;
+    const bool plain = a.Y2 != nullptr;
     int g = blockIdx.x;
     const int dt0 = (g % a.nd) * a.td; g /= a.nd;
     const int c0 = (g % a.nc) * a.tc; g /= a.nc;
@@ -130,7 +132,8 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
             const int ib = b0 + bb, ic = c0 + ro, id = dt0 + lane;
             if (lane < TD && ib < a.d1 && ic < a.d2 && id < a.d3) {
                 const float v = fmaxf(slot[bb * YROW + ro * P + lane + 1] + a.b2, 0.f);
-                unsafeAtomicAdd(Y + ((size_t)aout * a.d1 + ib) * nB + (size_t)ic * a.d3 + id, v);
+                float *dst = Y + ((size_t)aout * a.d1 + ib) * nB + (size_t)ic * a.d3 + id;
+                if (plain) *dst = v; else unsafeAtomicAdd(dst, v);
             }
         }
         __syncthreads();
@@ -477,10 +480,10 @@ bool nc_fused_fills_chip(int pairs, int d0, int d1, int d2, int d3) {
     return nc_fused_tile(a, pairs) >= 1024;
 }
 
-int launch_nc_fused(const float *X, float *Y, size_t stride, int pairs, int d0, int d1, int d2, int d3, const unsigned char *w_dev,
-                    float b2, const int *xmax, size_t xmax_stride, hipStream_t stream) {
+int launch_nc_fused(const float *X, float *Y, float *Y2, size_t stride, int pairs, int d0, int d1, int d2, int d3,
+                    const unsigned char *w_dev, float b2, const int *xmax, size_t xmax_stride, hipStream_t stream) {
     NcFusedArgs a{};
-    a.X = X; a.Y = Y; a.stride = stride; a.d0 = d0; a.d1 = d1; a.d2 = d2; a.d3 = d3; a.w = w_dev; a.b2 = b2;
+    a.X = X; a.Y = Y; a.Y2 = Y2; a.stride = stride; a.d0 = d0; a.d1 = d1; a.d2 = d2; a.d3 = d3; a.w = w_dev; a.b2 = b2;
     a.xmax = xmax; a.xmax_stride = xmax_stride;
     nc_fused_tile(a, pairs);
     const size_t lds = nc_fused_lds_bytes(a.tb, a.tc, a.P);
