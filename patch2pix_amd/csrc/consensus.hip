@@ -56,6 +56,11 @@ struct NcFusedArgs {
     size_t xmax_stride;
 };
 
+__host__ __device__ __forceinline__ int nc_yrow(int tc, int P) {
+    int r = (tc * P + 3) & ~3;            // 16-byte rows
+    while ((r & 63) != 4 && (r & 63) != 12 && (r & 63) != 20 && (r & 63) != 28 && (r & 63) != 36 && (r & 63) != 44 && (r & 63) != 52 && (r & 63) != 60) r += 4;
+    return r;
+}
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ unsigned short nf2h(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
 __device__ __forceinline__ float nh2f(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
@@ -80,7 +85,9 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     const int XPLANE = (9 * XROWS * P * 2 + 8 + 15) & ~15;   // bytes of one fp16 plane of the staged input (+ the window overrun of its
                                                              // last position; the hidden planes behind it need 16-byte alignment)
     const int HKH = HN * 16, HPLANE = 2 * HKH;               // hidden: [plane][channel half][position][8 x fp16]
-    const int YROW = TC * P, YSLOT = TB * YROW;              // accumulators: [3 slots][TB][TC * P] floats
+    // accumulators: [3 slots][TB][TC * P (+ pad)] floats; the pad (stride = 4 mod 8 floats... = 16 B mod 32 B, and never a
+    // multiple of 64 floats) spreads the nine planes a layer-2 tile adds into over the LDS banks
+    const int YROW = nc_yrow(TC, P), YSLOT = TB * YROW;
     unsigned char *Xs = sm;
     unsigned char *Hs = sm + 2 * XPLANE;
     unsigned char *W2s = Hs + 2 * HPLANE;                    // layer-2 B fragments
@@ -427,7 +434,7 @@ void pack_nc_fused(const float *w1, const float *b1, const float *w2, std::vecto
 }
 
 size_t nc_fused_lds_bytes(int tb, int tc, int P) {
-    return (size_t)2 * ((9 * (tc + 4) * P * 2 + 8 + 15) & ~15) + (size_t)2 * 2 * (std::max((tc + 2) * P, (((tc + 2) * P + 63) >> 6) * 64) + 2) * 16 + (size_t)3 * tb * tc * P * 4 + 256 + NCF_W2_BYTES;
+    return (size_t)2 * ((9 * (tc + 4) * P * 2 + 8 + 15) & ~15) + (size_t)2 * 2 * (std::max((tc + 2) * P, (((tc + 2) * P + 63) >> 6) * 64) + 2) * 16 + (size_t)3 * tb * nc_yrow(tc, P) * 4 + 256 + NCF_W2_BYTES;
 }
 
 // float bits of max |x| over n values per pair -> out[pair * out_stride] (zero beforehand); one atomic per wave
