@@ -218,6 +218,45 @@ int p2p_regress_batch_dev(const p2p_regressor *reg1, const p2p_regressor *reg2, 
                           float *matches1, float *probs1, float *raw1,
                           float *matches2, float *probs2, float *raw2, p2p_stream_t stream);
 
+/* ---- feature-pyramid producer (the convolutions of ResNet34 layer1..layer3) ------------------ */
+
+/* One Conv2d(ci, co, ks, stride, padding = ks / 2, bias = False) + BatchNorm2d(co) in eval mode -- reference
+ * networks/resnet.py:26-60 (BasicBlock: conv1/bn1, conv2/bn2, downsample) as used by forward_all (:138-157) with the
+ * layer3 stride patch (:169-173).  HOST pointers: weight [co,ci,ks,ks], the four BatchNorm vectors [co].  Supported:
+ * ks 1 or 3, stride 1 or 2, ci a multiple of 32, co a multiple of 64 (every convolution of layer1..layer3).
+ * Arithmetic: fp32-equivalent (operands as two fp16 planes under exact power-of-two scales, three MFMA products per
+ * fp32 product, fp32 accumulation).                                                                             */
+typedef struct p2p_conv p2p_conv;
+int p2p_conv_create(const float *weight, const p2p_bn_params *bn, int ci, int co, int ks, int stride, p2p_conv **out);
+void p2p_conv_destroy(p2p_conv *conv);
+
+/* y = [relu](bn(conv(x)) [+ residual]) for a batch of n images.  Activations are fp32 **NHWC** device arrays
+ * (x [n,h,w,ci], y and residual [n,ho,wo,co], ho = (h + 2 (ks/2) - ks) / stride + 1); xmax [n] holds the float bits of
+ * max |x| per image (p2p_absmax_batch, or the ymax of the producing call); ymax (optional, [n] int, **zero on entry**:
+ * the kernel raises it with atomicMax) receives the same for y.  The three steps of a BasicBlock: conv1 (relu = 1), downsample (relu = 0, when present), conv2 (residual =
+ * the block input or the downsample output, relu = 1).                                                           */
+int p2p_conv_forward(const p2p_conv *conv, const float *x, const int *xmax, int n, int h, int w, const float *residual,
+                     int relu, float *y, int *ymax, p2p_stream_t stream);
+
+/* The stem: Conv2d(3, 64, 7, stride 2, padding 3, bias = False) + BatchNorm2d(64) + ReLU -- reference
+ * networks/resnet.py:101-103 as used at :141-143.  HOST pointers: weight [64,3,7,7] + BatchNorm vectors.  image [n,3,h,w]
+ * NCHW fp32 (device), imax [n] float bits of max |image| per item; y [n,64,ho,wo] **NCHW** (pyramid level 1 as the fine
+ * stage reads it), ho = (h - 1) / 2 + 1.                                                                         */
+typedef struct p2p_stem p2p_stem;
+int p2p_stem_create(const float *weight, const p2p_bn_params *bn, p2p_stem **out);
+void p2p_stem_destroy(p2p_stem *stem);
+int p2p_stem_forward(const p2p_stem *stem, const float *image, const int *imax, int n, int h, int w, float *y, p2p_stream_t stream);
+
+/* MaxPool2d(kernel 3, stride 2, padding 1) -- reference networks/resnet.py:104,146: x [n,c,h,w] NCHW -> y [n,hp,wp,c]
+ * **NHWC** (hp = (h - 1) / 2 + 1), the input layout of p2p_conv_forward; ymax (optional, zero on entry) as there.  c a multiple of 64. */
+int p2p_maxpool_nhwc(const float *x, int n, int c, int h, int w, float *y, int *ymax, p2p_stream_t stream);
+
+/* [n,h,w,c] -> [n,c,h,w]: a pyramid level in the layout p2p_coarse_forward / p2p_regress read.                     */
+int p2p_nhwc_to_nchw(const float *x, int n, int h, int w, int c, float *y, p2p_stream_t stream);
+
+/* out[i] = float bits of max |x| over the count values of item i (items are count values apart).                 */
+int p2p_absmax_batch(const float *x, size_t count, int items, int *out, p2p_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -441,7 +441,12 @@ size_t nc_fused_lds_bytes(int tb, int tc, int P) {
 __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, size_t n, size_t stride, int *out, size_t out_stride) {
     x += (size_t)blockIdx.z * stride;
     float m = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    const size_t n4 = (((size_t)x & 15) == 0) ? n >> 2 : 0;          // 16-byte loads where the item starts aligned
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const nf4 v = ((const nf4 *)x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    for (size_t i = 4 * n4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
     int *dst = out + (size_t)blockIdx.z * out_stride;
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x
 }
 
 int launch_absmax(const float *x, size_t n, size_t stride, int pairs, int *out, size_t out_stride, hipStream_t stream) {
-    const unsigned blocks = (unsigned)std::min<size_t>((n + 2047) / 2048, 256);
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 4095) / 4096, 1024);
     hipLaunchKernelGGL(absmax_kernel, dim3(blocks, 1, pairs), dim3(256), 0, stream, x, n, stride, out, out_stride);
     return check_launch("absmax_kernel");
 }

@@ -1,13 +1,18 @@
-"""Feature-pyramid producer for the matching hot path (stays on PyTorch-ROCm / MIOpen).
+"""Feature-pyramid producer for the matching hot path.
 
 Role of reference networks/resnet.py:125-173 (ResNet34 truncated after layer3, with the
-layer3 stride patch of `change_stride`).  This is the *boundary* of the hot path
-(SURVEY.md section 8 row a20): it is deliberately left to PyTorch, the HIP library starts
-at its outputs.  Parameter names follow the torchvision ResNet convention so that
+layer3 stride patch of `change_stride`), SURVEY.md section 8 row f1.  The module keeps the torch
+parameters (checkpoints load unchanged); on the GPU in eval mode the 32 convolutions of
+stem and of layer1..layer3 run as the library's fp32-equivalent fp16 MFMA kernels (csrc/backbone.hip;
+NHWC activations between the layers, NCHW pyramid levels out), the max-pool as its own kernel.
+`P2P_BACKBONE=miopen` selects the all-PyTorch path (the round-1/2 producer).  Parameter names follow the torchvision ResNet convention so that
 reference checkpoints (`extract.*` keys, utils/train/helper.py:10-17) load unchanged;
 `layer4.*` keys of a checkpoint are never used by the path (reference
 networks/patch2pix.py:72-74 freezes them as "never used") and are skipped on load.
 """
+import os
+
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -55,8 +60,54 @@ class ResNet34(nn.Module):
         for conv in (blk.conv1, blk.conv2, blk.downsample[0]):
             conv.stride = (1, 1)
 
+    def __getstate__(self):
+        """copy.deepcopy / pickling: the packed device-side weights are a cache, not part of the module."""
+        state = self.__dict__.copy()
+        state.pop("_hip_trunk_cache", None)
+        state.pop("_hip_sig", None)
+        return state
+
+    def _hip_trunk(self, device):
+        """The packed convolutions of layer1..layer3 for `device`, re-packed when a parameter changed."""
+        from .. import ops
+        sig = (str(device),) + tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
+        if getattr(self, "_hip_sig", None) != sig:
+            def pack(conv, bn):
+                return ops.ConvBN(conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.stride[0], device)
+            trunk = []
+            for name, _, _, _ in _STAGES:
+                blocks = []
+                for blk in getattr(self, name):
+                    down = pack(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
+                    blocks.append((pack(blk.conv1, blk.bn1), pack(blk.conv2, blk.bn2), down))
+                trunk.append(blocks)
+            stem = ops.Stem(self.conv1.weight, self.bn1.weight, self.bn1.bias, self.bn1.running_mean, self.bn1.running_var, device)
+            self._hip_trunk_cache, self._hip_sig = (stem, trunk), sig
+        return self._hip_trunk_cache
+
+    def _pyramid_hip(self, x):
+        from .. import ops
+        stem, trunk = self._hip_trunk(x.device)
+        feats = [x]
+        x = stem.forward(x)
+        feats.append(x)
+        # float bits of max |activation| per image, one row per layer output: raised by the producing kernel (atomicMax)
+        maxima = torch.zeros((1 + 2 * sum(len(b) for b in trunk), x.shape[0]), device=x.device, dtype=torch.int32)
+        xmax, row = maxima[0], 1
+        x = ops.maxpool_nhwc(x, xmax)                                          # NHWC from here on
+        for blocks in trunk:
+            for conv1, conv2, down in blocks:
+                skip = x if down is None else down.forward(x, xmax, relu=False)
+                y = conv1.forward(x, xmax, ymax=maxima[row])
+                x = conv2.forward(y, maxima[row], residual=skip, ymax=maxima[row + 1])
+                xmax, row = maxima[row + 1], row + 2
+            feats.append(ops.nhwc_to_nchw(x))
+        return feats
+
     def pyramid(self, x):
         """[image, relu(bn1(conv1)), layer1, layer2, layer3] -- reference forward_all (resnet.py:138-157)."""
+        if x.is_cuda and not self.training and os.environ.get("P2P_BACKBONE", "hip") != "miopen":
+            return self._pyramid_hip(x)
         feats = [x]
         x = F.relu(self.bn1(self.conv1(x)), inplace=True)
         feats.append(x)

@@ -40,6 +40,102 @@ class NcnWeights:
             self.handle = None
 
 
+class ConvBN:
+    """Device-resident packed Conv2d(bias=False) + BatchNorm2d (eval) of the pyramid producer
+    (reference networks/resnet.py:26-60); `forward` works on fp32 NHWC activations."""
+
+    def __init__(self, conv_weight, bn_weight, bn_bias, bn_mean, bn_var, stride, device):
+        keep = [_host(t) for t in (conv_weight, bn_weight, bn_bias, bn_mean, bn_var)]
+        co, ci, ks, ks2 = keep[0].shape
+        if ks != ks2:
+            raise NotImplementedError("square kernels only")
+        bn = _lib.BnParams(*[t.data_ptr() for t in keep[1:]])
+        self.handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.p2p_conv_create(keep[0].data_ptr(), ctypes.byref(bn), ci, co, ks, int(stride), ctypes.byref(self.handle)),
+                       "p2p_conv_create")
+        self.ci, self.co, self.ks, self.stride = ci, co, ks, int(stride)
+        self.device = torch.device(device)
+
+    def __del__(self):
+        if getattr(self, "handle", None) and _lib is not None:
+            _lib.p2p_conv_destroy(self.handle)
+            self.handle = None
+
+    def forward(self, x, xmax, residual=None, relu=True, ymax=None):
+        """x [n,h,w,ci] fp32 NHWC, xmax [n] int32 (float bits of max |x| per image) -> y [n,ho,wo,co]; ymax (optional
+        [n] int32, ZERO on entry) receives the float bits of max |y| per image."""
+        n, h, w, ci = x.shape
+        if ci != self.ci or x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous():
+            raise TypeError(f"ConvBN.forward: expected a contiguous float32 NHWC tensor with {self.ci} channels on the GPU")
+        pad = self.ks // 2
+        ho, wo = (h + 2 * pad - self.ks) // self.stride + 1, (w + 2 * pad - self.ks) // self.stride + 1
+        y = torch.empty((n, ho, wo, self.co), device=x.device, dtype=torch.float32)
+        if residual is not None and (residual.shape != y.shape or not residual.is_contiguous()):
+            raise TypeError("ConvBN.forward: residual must be a contiguous NHWC tensor of the output's shape")
+        _lib.check(_lib.p2p_conv_forward(self.handle, x.data_ptr(), xmax.data_ptr(), n, h, w,
+                                         residual.data_ptr() if residual is not None else None, int(relu), y.data_ptr(),
+                                         ymax.data_ptr() if ymax is not None else None, _stream()), "p2p_conv_forward")
+        return y
+
+
+class Stem:
+    """Device-resident packed conv1 7x7/2 + bn1 (+ ReLU) of the pyramid producer (reference networks/resnet.py:101-103)."""
+
+    def __init__(self, conv_weight, bn_weight, bn_bias, bn_mean, bn_var, device):
+        keep = [_host(t) for t in (conv_weight, bn_weight, bn_bias, bn_mean, bn_var)]
+        if tuple(keep[0].shape) != (64, 3, 7, 7):
+            raise NotImplementedError("only the ResNet stem Conv2d(3, 64, 7, 2, 3) is implemented")
+        bn = _lib.BnParams(*[t.data_ptr() for t in keep[1:]])
+        self.handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.p2p_stem_create(keep[0].data_ptr(), ctypes.byref(bn), ctypes.byref(self.handle)), "p2p_stem_create")
+        self.device = torch.device(device)
+
+    def __del__(self):
+        if getattr(self, "handle", None) and _lib is not None:
+            _lib.p2p_stem_destroy(self.handle)
+            self.handle = None
+
+    def forward(self, image):
+        """image [n,3,h,w] fp32 NCHW -> relu(bn1(conv1(image))) [n,64,ho,wo] NCHW."""
+        image = _f32c(image, "image")
+        n, c, h, w = image.shape
+        if c != 3:
+            raise TypeError("Stem.forward: three-channel images only")
+        imax = absmax_batch(image)
+        y = torch.empty((n, 64, (h - 1) // 2 + 1, (w - 1) // 2 + 1), device=image.device, dtype=torch.float32)
+        _lib.check(_lib.p2p_stem_forward(self.handle, image.data_ptr(), imax.data_ptr(), n, h, w, y.data_ptr(), _stream()), "p2p_stem_forward")
+        return y
+
+
+def maxpool_nhwc(x, ymax=None):
+    """MaxPool2d(3, 2, 1) of x [n,c,h,w] NCHW -> y [n,hp,wp,c] NHWC; ymax: optional [n] int32, ZERO on entry."""
+    x = _f32c(x, "x")
+    n, c, h, w = x.shape
+    y = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.p2p_maxpool_nhwc(x.data_ptr(), n, c, h, w, y.data_ptr(), ymax.data_ptr() if ymax is not None else None, _stream()),
+               "p2p_maxpool_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x):
+    """x [n,h,w,c] -> [n,c,h,w] contiguous."""
+    x = _f32c(x, "x")
+    n, h, w, c = x.shape
+    y = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.p2p_nhwc_to_nchw(x.data_ptr(), n, h, w, c, y.data_ptr(), _stream()), "p2p_nhwc_to_nchw")
+    return y
+
+
+def absmax_batch(x):
+    """x [n, ...] contiguous fp32 on the GPU -> [n] int32: float bits of max |x| per item."""
+    x = _f32c(x, "x")
+    out = torch.empty((x.shape[0],), device=x.device, dtype=torch.int32)
+    _lib.check(_lib.p2p_absmax_batch(x.data_ptr(), x[0].numel(), x.shape[0], out.data_ptr(), _stream()), "p2p_absmax_batch")
+    return out
+
+
 class RegressorWeights:
     """Device-resident packed FeatRegressNet (reference networks/modules.py:56-112).
     `sd` maps the sub-state_dict keys ('conv.0.weight', 'fc.6.bias', ...) to tensors."""

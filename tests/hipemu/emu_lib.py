@@ -156,3 +156,52 @@ def match_tail_batch(emu, fine, scores, coarse, counts, scale, io_thres):
                                         ptr(om), ptr(osc), ptr(oc), ptr(on), None), "p2p_match_tail_batch")
     return [None if int(on[b]) < 0 else (om[b, :int(on[b])].clone(), osc[b, :int(on[b])].clone(), oc[b, :int(on[b])].clone())
             for b in range(nb)]
+
+
+def _bn(bn):
+    return real.BnParams(*[t.data_ptr() for t in bn])
+
+
+def conv_bn(emu, weight, bn, stride, x_nchw, residual_nchw=None, relu=True):
+    """p2p_conv_create + p2p_absmax_batch + p2p_conv_forward on CPU tensors (NCHW in and out; the kernel works on NHWC).
+    -> (y [n,co,ho,wo], float max |y| per image as the kernel reports it)."""
+    co, ci, ks, _ = weight.shape
+    keep = [weight.contiguous()] + [t.contiguous() for t in bn]
+    b = _bn(keep[1:])
+    h = ctypes.c_void_p()
+    check(emu, emu.p2p_conv_create(ptr(keep[0]), ctypes.byref(b), ci, co, ks, stride, ctypes.byref(h)), "p2p_conv_create")
+    n, _, hh, ww = x_nchw.shape
+    x = x_nchw.permute(0, 2, 3, 1).contiguous()
+    xmax = torch.zeros(n, dtype=torch.int32)
+    check(emu, emu.p2p_absmax_batch(ptr(x), hh * ww * ci, n, ptr(xmax), None), "p2p_absmax_batch")
+    pad = ks // 2
+    ho, wo = (hh + 2 * pad - ks) // stride + 1, (ww + 2 * pad - ks) // stride + 1
+    y = torch.empty(n, ho, wo, co)
+    ymax = torch.zeros(n, dtype=torch.int32)
+    res = residual_nchw.permute(0, 2, 3, 1).contiguous() if residual_nchw is not None else None
+    check(emu, emu.p2p_conv_forward(h, ptr(x), ptr(xmax), n, hh, ww, ptr(res), int(relu), ptr(y), ptr(ymax), None), "p2p_conv_forward")
+    emu.p2p_conv_destroy(h)
+    return y.permute(0, 3, 1, 2).contiguous(), ymax.view(torch.float32)
+
+
+def stem_pool(emu, weight, bn, image):
+    """p2p_stem_forward, p2p_maxpool_nhwc, p2p_nhwc_to_nchw -> (level 1 NCHW, pooled NHWC, pooled NCHW, pooled max)."""
+    keep = [weight.contiguous()] + [t.contiguous() for t in bn]
+    b = _bn(keep[1:])
+    h = ctypes.c_void_p()
+    check(emu, emu.p2p_stem_create(ptr(keep[0]), ctypes.byref(b), ctypes.byref(h)), "p2p_stem_create")
+    image = image.contiguous()
+    n, _, hh, ww = image.shape
+    imax = torch.zeros(n, dtype=torch.int32)
+    check(emu, emu.p2p_absmax_batch(ptr(image), 3 * hh * ww, n, ptr(imax), None), "p2p_absmax_batch")
+    ho, wo = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+    y = torch.empty(n, 64, ho, wo)
+    check(emu, emu.p2p_stem_forward(h, ptr(image), ptr(imax), n, hh, ww, ptr(y), None), "p2p_stem_forward")
+    emu.p2p_stem_destroy(h)
+    hp, wp = (ho - 1) // 2 + 1, (wo - 1) // 2 + 1
+    pooled = torch.empty(n, hp, wp, 64)
+    pmax = torch.zeros(n, dtype=torch.int32)
+    check(emu, emu.p2p_maxpool_nhwc(ptr(y), n, 64, ho, wo, ptr(pooled), ptr(pmax), None), "p2p_maxpool_nhwc")
+    back = torch.empty(n, 64, hp, wp)
+    check(emu, emu.p2p_nhwc_to_nchw(ptr(pooled), n, hp, wp, 64, ptr(back), None), "p2p_nhwc_to_nchw")
+    return y, pooled, back, pmax.view(torch.float32)

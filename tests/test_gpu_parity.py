@@ -281,7 +281,7 @@ def test_predict_fine_golden(name, dev):
 
 @pytest.mark.parametrize("name", ["estimate_matches_240x320", "estimate_matches_imsize256"])
 def test_estimate_matches_golden(name, dev, tmp_path):
-    """The drop-in entry point on image files.  The backbone here runs on the GPU (MIOpen) while the
+    """The drop-in entry point on image files.  The backbone here runs on the GPU (HIP convolutions, csrc/backbone.hip) while the
     golden run used the CPU, so a small fraction of coarse argmaxes may legitimately differ;
     rows are compared by coarse match."""
     from PIL import Image
@@ -302,7 +302,7 @@ def test_estimate_matches_golden(name, dev, tmp_path):
     assert len(hits) >= 0.8 * len(g["fine_coarse"]), f"only {len(hits)} of {len(g['fine_coarse'])} coarse matches agree"
     gi = np.array([h[0] for h in hits]); ri = np.array([h[1] for h in hits])
     err = np.abs(m[gi] - g["fine_matches"][ri]).max(axis=1)
-    # backbone numerics differ (MIOpen vs CPU): the regressed coordinates agree to well below a pixel
+    # backbone numerics differ (GPU vs CPU summation order): the regressed coordinates agree to well below a pixel
     assert np.median(err) < 0.05 and (err < 0.5).mean() > 0.9
     mc, sc, cc = model_helper.estimate_matches(net, str(tmp_path / "1.png"), str(tmp_path / "2.png"), ksize=2,
                                                ncn_thres=0.0, eval_type="coarse", imsize=imsize)
@@ -820,7 +820,7 @@ def test_real_image_pairs(name, imsize, dev, capsys):
         err = np.abs(m[gi] - g["fine_matches"][ri]).max(axis=1)
         mma3 = float((err < 3.0).mean() * frac)
         with capsys.disabled():
-            print(f"{name}: entry point (backbone on MIOpen): {len(c)} matches, reference {len(g['fine_coarse'])}; "
+            print(f"{name}: entry point (pyramid produced on the GPU): {len(c)} matches, reference {len(g['fine_coarse'])}; "
                   f"{frac:.3f} of the reference's coarse matches reproduced; of those: median |d| {np.median(err):.2e} px, max {err.max():.2e} px, "
                   f"within 1e-3 px {float((err < 1e-3).mean()):.3f}, within 3 px {float((err < 3).mean()):.3f}; "
                   f"MMA@3px-style agreement (reference = ground truth) {mma3:.3f}")
@@ -1110,3 +1110,82 @@ def test_device_normalisation_is_bit_identical(dev):
     host = _normalised(Image.fromarray(px))
     got = normalise_pixels(torch.from_numpy(px)[None].to(dev))[0].cpu()
     assert torch.equal(host, got)
+
+
+# ---- pyramid producer: the HIP convolutions of conv1 ... layer3 against torch ---------------------------
+def _extract(dev, seed=0):
+    from patch2pix_amd.networks import resnet
+    net = resnet.ResNet34()
+    net.change_stride("layer3")
+    sd = synthetic.make_state_dict(seed)
+    net.load_state_dict({k[len("extract."):]: v for k, v in sd.items() if k.startswith("extract.") and "layer4" not in k}, strict=False)
+    return net.eval()
+
+
+def _image_batch(seeds, h, w):
+    ims = [synthetic.make_image_pair(s, h, w)[0] for s in seeds]
+    x = torch.stack([torch.from_numpy(a).permute(2, 0, 1).float() / 255.0 for a in ims])
+    mean, std = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    return (x - mean) / std
+
+
+@pytest.mark.parametrize("hw", [(96, 128), (101, 135), (240, 320)])
+def test_backbone_pyramid_vs_fp64(hw, dev, monkeypatch, capsys):
+    """Every level of the pyramid against the same module evaluated in fp64 on the CPU: the HIP producer has to be as close to
+    it as the fp32 library path (MIOpen) is -- both are fp32-accumulating evaluations of the same sums (reference
+    networks/resnet.py:138-157)."""
+    net = _extract(dev)
+    x = _image_batch([3, 4], *hw)
+    with torch.no_grad():
+        ref = [t for t in net.double().pyramid(x.double())]
+        net = net.float().to(dev)
+        monkeypatch.setenv("P2P_BACKBONE", "hip")
+        got = net.pyramid(x.to(dev))
+        monkeypatch.setenv("P2P_BACKBONE", "miopen")
+        lib = net.pyramid(x.to(dev))
+    assert len(got) == 5 and torch.equal(got[0].cpu(), x)
+    rows = []
+    for lv in range(1, 5):
+        assert got[lv].shape == ref[lv].shape and got[lv].is_contiguous() and got[lv].dtype == torch.float32
+        scale = ref[lv].abs().amax(dim=(1, 2, 3), keepdim=True)
+        e_hip = ((got[lv].cpu().double() - ref[lv]).abs() / scale).max().item()
+        e_lib = ((lib[lv].cpu().double() - ref[lv]).abs() / scale).max().item()
+        rows.append((e_hip, e_lib))
+        assert e_hip <= max(3e-6, 2.5 * e_lib), f"level {lv}: HIP {e_hip:.2e} vs MIOpen {e_lib:.2e} of the largest value"
+    with capsys.disabled():
+        print(f"\npyramid {hw}: max |err| / max |ref| per level, HIP / MIOpen: " + "  ".join(f"{a:.1e} / {b:.1e}" for a, b in rows))
+
+
+def test_backbone_batch_and_tile_independence(dev, monkeypatch):
+    """An image's pyramid does not depend on its batch mates (operand scales are per image) nor on the tile the launch
+    heuristic picks (every tile sums an output's K axis in the same order): bit-identical."""
+    net = _extract(dev).to(dev)
+    x = _image_batch([5, 6, 7], 120, 168).to(dev)
+    x[1] *= 40.0                                                     # a batch mate on a very different scale
+    monkeypatch.setenv("P2P_BACKBONE", "hip")
+    with torch.no_grad():
+        full = net.pyramid(x)
+        for i in range(3):
+            one = net.pyramid(x[i:i + 1].contiguous())
+            for lv in range(1, 5):
+                assert torch.equal(one[lv][0], full[lv][i]), f"image {i} level {lv}"
+        for tile in ("2,4,2", "1,4,2", "2,2,2", "1,2,2"):
+            monkeypatch.setenv("P2P_CONV_TILE", tile)
+            other = net.pyramid(x)
+            for lv in range(1, 5):
+                assert torch.equal(other[lv], full[lv]), f"tile {tile} level {lv}"
+
+
+def test_backbone_full_size_vs_library(dev, monkeypatch):
+    """480x640 (the benchmark's image size), two images: HIP producer against the MIOpen evaluation of the same module."""
+    net = _extract(dev).to(dev)
+    x = _image_batch([8, 9], 480, 640).to(dev)
+    with torch.no_grad():
+        monkeypatch.setenv("P2P_BACKBONE", "hip")
+        got = net.pyramid(x)
+        monkeypatch.setenv("P2P_BACKBONE", "miopen")
+        lib = net.pyramid(x)
+    for lv in range(1, 5):
+        assert got[lv].shape == lib[lv].shape
+        scale = lib[lv].abs().amax(dim=(1, 2, 3), keepdim=True)
+        assert ((got[lv] - lib[lv]).abs() / scale).max().item() < 1e-5

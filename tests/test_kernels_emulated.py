@@ -400,3 +400,65 @@ torch.save((corr, delta, m, s), sys.argv[1])
     a, b = torch.load(f), outs["fp16x2"]
     assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     assert torch.allclose(a[0], b[0], rtol=2e-4, atol=1e-9) and torch.allclose(a[3], b[3], rtol=1e-4)
+
+
+# ---- pyramid producer (csrc/backbone.hip): every layer type of ResNet34 conv1 ... layer3 against torch in fp64 -----------
+# The kernels are fp32-equivalent (operands to within 2^-24, fp32 accumulation); the emulated MFMA sums its K values one
+# after the other in fp32, which is the worst summation order there is: errors of ~1e-6 of the largest output against
+# 2-4e-7 for torch's blocked fp32 convolution.  On the MI355X the two are level (tests/test_gpu_parity.py).
+BACKBONE_TOL = 4e-6
+
+
+def _bn_params(co, gen):
+    return [torch.rand(co, generator=gen) + 0.5, torch.randn(co, generator=gen) * 0.1, torch.randn(co, generator=gen) * 0.1,
+            torch.rand(co, generator=gen) + 0.5]
+
+
+def _bn_eval64(t, bn):
+    g, b, m, v = [q.double().view(1, -1, 1, 1) for q in bn]
+    return (t - m) / torch.sqrt(v + 1e-5) * g + b
+
+
+@pytest.mark.parametrize("ci,co,ks,stride,n,h,w,res,relu,tile", [
+    (64, 64, 3, 1, 2, 11, 19, True, True, None),           # layer1 block convolution (+ identity skip), two images of different scale
+    (64, 128, 3, 2, 2, 13, 21, False, True, None),         # layer2[0].conv1: stride 2, odd extents
+    (64, 128, 1, 2, 1, 13, 21, False, False, None),        # layer2[0].downsample: 1x1 stride 2, no ReLU
+    (128, 128, 3, 1, 1, 9, 17, True, True, "2,2,2"),       # layer2, the large tile of a 128-channel layer
+    (128, 256, 3, 1, 1, 9, 17, False, True, "2,4,2"),      # layer3[0].conv1 (stride patched to 1), the large tile
+    (128, 256, 1, 1, 3, 7, 18, False, False, None),        # layer3[0].downsample
+    (256, 256, 3, 1, 1, 5, 16, True, True, "1,4,2"),
+    (256, 256, 3, 1, 1, 10, 16, True, True, "2,2,2"),
+])
+def test_backbone_convolution_against_torch(ci, co, ks, stride, n, h, w, res, relu, tile, emu, monkeypatch):
+    if tile:
+        monkeypatch.setenv("P2P_CONV_TILE", tile)
+    gen = torch.Generator().manual_seed(ci * 7 + co + ks + stride)
+    wt = torch.randn(co, ci, ks, ks, generator=gen) * (2.0 / (ci * ks * ks)) ** 0.5
+    bn = _bn_params(co, gen)
+    x = torch.relu(torch.randn(n, ci, h, w, generator=gen)) * torch.tensor([1.0, 37.0, 0.003][:n]).view(n, 1, 1, 1)
+    ref = _bn_eval64(torch.nn.functional.conv2d(x.double(), wt.double(), None, stride, ks // 2), bn)
+    skip = torch.randn(n, co, ref.shape[2], ref.shape[3], generator=gen) * ref.abs().amax(dim=(1, 2, 3), keepdim=True).float() if res else None
+    if res:
+        ref = ref + skip.double()
+    if relu:
+        ref = ref.relu()
+    got, gmax = emu_lib.conv_bn(emu, wt, bn, stride, x, skip, relu)
+    assert got.shape == ref.shape
+    scale = ref.abs().amax(dim=(1, 2, 3), keepdim=True)
+    assert ((got.double() - ref).abs() / scale).max().item() < BACKBONE_TOL
+    assert torch.equal(gmax, got.abs().amax(dim=(1, 2, 3)))          # what the next layer scales its operands by
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 37, 70), (1, 16, 130), (1, 64, 64)])
+def test_backbone_stem_pool_transpose_against_torch(n, h, w, emu):
+    gen = torch.Generator().manual_seed(h * w)
+    wt = torch.randn(64, 3, 7, 7, generator=gen) * 0.1
+    bn = _bn_params(64, gen)
+    image = torch.randn(n, 3, h, w, generator=gen) * 1.3
+    level1, pooled, back, pmax = emu_lib.stem_pool(emu, wt, bn, image)
+    ref = _bn_eval64(torch.nn.functional.conv2d(image.double(), wt.double(), None, 2, 3), bn).relu()
+    assert level1.shape == ref.shape
+    assert ((level1.double() - ref).abs().max() / ref.abs().max()).item() < BACKBONE_TOL
+    want = torch.nn.functional.max_pool2d(level1, 3, 2, 1)           # max-pool and transposition are exact
+    assert torch.equal(pooled.permute(0, 3, 1, 2), want) and torch.equal(back, want)
+    assert torch.equal(pmax, want.abs().amax(dim=(1, 2, 3)))
