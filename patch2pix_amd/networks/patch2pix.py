@@ -268,7 +268,7 @@ class Patch2Pix(nn.Module):
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=self.device)
         main = torch.cuda.current_stream(self.device)
-        ready = torch.cuda.Event()
+        ready = torch.cuda.Event(blocking=True)
         ready.record(main)
         # pinned staging buffers are recycled (allocating pinned memory synchronises with the device)
         key = (tuple(matches_.shape), self._pin_turn)
@@ -290,7 +290,7 @@ class Patch2Pix(nn.Module):
             self._copy_stream.wait_event(ready)
             host_m.copy_(matches_, non_blocking=True)
             host_s.copy_(score_, non_blocking=True)
-            done = torch.cuda.Event()
+            done = torch.cuda.Event(blocking=True)
             done.record(self._copy_stream)
         ticket = dict(feats1=feats1, feats2=feats2, matches=matches_, scores=score_, host=(host_m, host_s), done=done)
         slot[2] = ticket

@@ -92,6 +92,6 @@ def _pinned(n, device):
         cap = max(1024, 1 << (max(n, 1) - 1).bit_length())
         with torch.cuda.device(device):
             buf = (torch.empty((cap, 4), dtype=torch.int64).pin_memory(), torch.empty((cap,), dtype=torch.float32).pin_memory(),
-                   torch.cuda.Event())
+                   torch.cuda.Event(blocking=True))
         ring[0][slot] = buf
     return buf

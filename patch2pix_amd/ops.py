@@ -334,6 +334,33 @@ def filter_coarse_batch(matches, scores, ncn_thres=0.0, mutual=True):
     return out_m, out_s, counts
 
 
+_small_rings = {}      # device index -> [ring of 8 [pinned byte buffer, event], turn]
+
+
+def small_to_device(array, dtype, device):
+    """A small host array -> device tensor through a ring of pinned staging buffers (per device), asynchronously.  A copy
+    from pageable memory makes the host wait for everything queued on the stream before it; a caller that pipelines
+    batches must never do that."""
+    t = torch.as_tensor(array, dtype=dtype).contiguous()
+    device = torch.device(device)
+    nbytes = t.numel() * t.element_size()
+    ring = _small_rings.setdefault(device.index if device.index is not None else torch.cuda.current_device(), [[None] * 8, 0])
+    slot = ring[1] % 8
+    ring[1] += 1
+    buf = ring[0][slot]
+    if buf is not None:
+        buf[1].synchronize()               # the upload that last read this buffer has completed
+    if buf is None or buf[0].numel() < nbytes:
+        with torch.cuda.device(device):
+            buf = [torch.empty((max(4096, nbytes),), dtype=torch.uint8).pin_memory(), torch.cuda.Event(blocking=True)]
+        ring[0][slot] = buf
+    host = buf[0][:nbytes].view(dtype).view(t.shape)
+    host.copy_(t)
+    out = host.to(device, non_blocking=True)
+    buf[1].record(torch.cuda.current_stream(device))
+    return out
+
+
 def match_tail_batch(fine, scores, coarse, counts, scale, io_thres):
     """The tail of estimate_matches (utils/eval/model_helper.py:92-109) on the device for padded batch outputs:
     fine [B,n,4] fp32, scores [B,n] fp32, coarse [B,n,4] int64, counts int32 [B] (device), scale [B,4] float64 ->
@@ -344,7 +371,8 @@ def match_tail_batch(fine, scores, coarse, counts, scale, io_thres):
     fine, scores, coarse = fine.contiguous(), _f32c(scores, "scores"), coarse.contiguous()
     nb, n, _ = fine.shape
     dev = fine.device
-    scale = torch.as_tensor(scale, dtype=torch.float64).reshape(nb, 4).to(dev)
+    scale = scale.to(torch.float64).reshape(nb, 4) if torch.is_tensor(scale) and scale.is_cuda else \
+        small_to_device(torch.as_tensor(scale, dtype=torch.float64).reshape(nb, 4), torch.float64, dev)
     out_m = torch.empty((nb, n, 4), dtype=torch.float64, device=dev)
     out_c = torch.empty((nb, n, 4), dtype=torch.float64, device=dev)
     out_s = torch.empty((nb, n), dtype=torch.float32, device=dev)

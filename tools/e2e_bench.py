@@ -14,7 +14,7 @@ from patch2pix_amd.utils import synthetic  # noqa: E402
 from patch2pix_amd.utils.eval import model_helper  # noqa: E402
 
 
-def measure(net, H=480, W=640, pairs=4, reps=3, stream_pairs=32):
+def measure(net, H=480, W=640, pairs=4, reps=3, stream_pairs=160):
     """-> {per_pair_pairs_per_s, stream_pairs_per_s, backbone_ms_per_image, ...}; jpeg inputs (quality 95)."""
     from patch2pix_amd.utils.eval.stream import estimate_matches_stream
     out = {"input": f"{H}x{W} JPEG files, estimate_matches(ksize=2, io_thres=0.25); random-init weights, so the number of "
@@ -42,13 +42,13 @@ def measure(net, H=480, W=640, pairs=4, reps=3, stream_pairs=32):
         out["per_pair_matches_last"] = int(m.shape[0])
         # streaming form: threaded loading, batched backbone, shared fine launch
         work = (paths[:8] * (stream_pairs // 8 + 1))[:stream_pairs]
-        list(estimate_matches_stream(net, paths[:8], batch=8, workers=16))
+        list(estimate_matches_stream(net, (paths[:8] * 5), batch=8, workers=4))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        nres = sum(1 for _ in estimate_matches_stream(net, work, batch=8, workers=16))
+        nres = sum(1 for _ in estimate_matches_stream(net, work, batch=8, workers=4))
         torch.cuda.synchronize()
         out["stream_pairs_per_s"] = nres / (time.perf_counter() - t0)
-        out["stream"] = "estimate_matches_stream(batch=8, workers=16)"
+        out["stream"] = f"estimate_matches_stream(batch=8, workers=4) over {nres} pairs: loader threads, HIP pyramid producer, device-side filter / fine stage / tail, three batches in flight"
     # single-pair latency, images already on the device: eager (host-side filter_coarse, ~700 launches) against the
     # whole path -- backbone, coarse stage, device-side filter, both regressors -- replayed as one hipGraph
     try:
@@ -79,6 +79,14 @@ def measure(net, H=480, W=640, pairs=4, reps=3, stream_pairs=32):
             out["hipgraph_proposals"] = int(g.out[3][0])
     except Exception as e:      # informational
         out["latency_error"] = repr(e)
+    try:
+        from tools import stream_breakdown
+        st = stream_breakdown.main(H, W, 8, streams=False)
+        out["stages_of_a_batch_of_8_pairs_ms"] = {k: round(v, 3) for k, v in st.items() if k.endswith("_ms") or k.startswith("load_ms")}
+        out["stages_note"] = ("each stage timed alone and synchronised; load_ms_per_pair_one_thread = PIL decode + resize of both "
+                              f"images on one loader thread; {st['proposals_per_pair']:.0f} proposals per pair (the model's own mutual matches)")
+    except Exception as e:      # informational
+        out["stages_error"] = repr(e)
     im = torch.randn(2, 3, H, W, device=net.device)
     with torch.no_grad():
         for _ in range(3):
