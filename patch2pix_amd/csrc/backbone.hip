@@ -63,7 +63,8 @@ __device__ __forceinline__ void bb_split(const f32x4 &xa, const f32x4 &xb, float
 
 // MT m-tiles (32 pixels = 2 rows x 16 columns) x NT n-tiles (32 channels) per wave, WN waves along the channels (4 / WN
 // along the rows), NIT staged 8-channel pieces per thread and chunk
-template <int MT, int NT, int WN, int NIT>
+// DB: slabs of weights in flight (ring of register sets; 3 for the small tiles of 3x3 convolutions, whose slabs are short)
+template <int MT, int NT, int WN, int NIT, int DB>
 __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
     P2P_DYN_SHARED(unsigned char, sm);
     constexpr int WM = 4 / WN, TH = 2 * MT * WM, TW = 16;
@@ -142,12 +143,15 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 bq[NT][2];
+    constexpr bool INPLACE = DB > 1 || MT * NT >= 8;
+    f32x4 bq[DB][NT][2];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        bq[j][0] = *(const f32x4 *)(wb + j * 2048);
-        bq[j][1] = *(const f32x4 *)(wb + j * 2048 + 1024);
-    }
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            bq[d][j][0] = *(const f32x4 *)(wb + d * wstep + j * 2048);
+            bq[d][j][1] = *(const f32x4 *)(wb + d * wstep + j * 2048 + 1024);
+        }
     stage_load(0);
     stage_commit(0);
     __syncthreads();
@@ -162,62 +166,66 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
             av[i][1] = *(const f32x4 *)(buf + PLB + abase[i]);
         }
         int tyy = 0, txx = 0, sl = 0;
-        for (int s = 0; s < nsl; ++s) {
-            // fragments of the next slab (the last one re-reads itself)
-            if (s + 1 < nsl) {
-                if (++sl == SPC) { sl = 0; if (++txx == KS) { txx = 0; ++tyy; } }
-            }
-            const int naoff = (tyy * IW + txx) * PS + sl * 32;
-            f32x4 na[MT][2];
+        for (int s = 0; s < nsl; s += DB) {                   // (DB divides the slabs of a chunk: host side)
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                na[i][0] = *(const f32x4 *)(buf + abase[i] + naoff);
-                na[i][1] = *(const f32x4 *)(buf + PLB + abase[i] + naoff);
-            }
-            wb += wstep;                                      // (one slab of zeros follows the last one)
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (MT * NT >= 8) {
-                // 128 accumulator registers leave no room for a second set of weights: a unit (n-tile) is re-loaded in place
-                // right after its six MFMAs, three units = 18 MFMAs ahead of its next use.  (sched_barrier: the scheduler
-                // would otherwise order the MFMAs by product and issue all the loads at the end of the slab.)
+            for (int d = 0; d < DB; ++d) {
+                // pixel fragments of the next slab (the last one of the chunk re-reads itself)
+                if (s + d + 1 < nsl) {
+                    if (++sl == SPC) { sl = 0; if (++txx == KS) { txx = 0; ++tyy; } }
+                }
+                const int naoff = (tyy * IW + txx) * PS + sl * 32;
+                f32x4 na[MT][2];
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
+                for (int i = 0; i < MT; ++i) {
+                    na[i][0] = *(const f32x4 *)(buf + abase[i] + naoff);
+                    na[i][1] = *(const f32x4 *)(buf + PLB + abase[i] + naoff);
+                }
+                wb += wstep;                                  // (DB slabs of zeros follow the last one)
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (INPLACE) {
+                    // a unit (n-tile) of weights is re-loaded in place right after its MFMAs, for the slab DB further on:
+                    // the large tile has no registers for a second set (128 accumulators) and is 18 MFMAs ahead with
+                    // DB = 1, the small ones keep three slabs in flight.  (sched_barrier: the scheduler would otherwise order
+                    // the MFMAs by product and issue all the loads at the end of the slab.)
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) acc[i][j] = BB_MFMA(av[i][1], bq[j][0], acc[i][j]);
+                    for (int j = 0; j < NT; ++j) {
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) acc[i][j] = BB_MFMA(av[i][0], bq[j][1], acc[i][j]);
+                        for (int i = 0; i < MT; ++i) acc[i][j] = BB_MFMA(av[i][1], bq[d][j][0], acc[i][j]);
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) acc[i][j] = BB_MFMA(av[i][0], bq[j][0], acc[i][j]);
-                    bq[j][0] = *(const f32x4 *)(wb + j * 2048);
-                    bq[j][1] = *(const f32x4 *)(wb + j * 2048 + 1024);
+                        for (int i = 0; i < MT; ++i) acc[i][j] = BB_MFMA(av[i][0], bq[d][j][1], acc[i][j]);
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) acc[i][j] = BB_MFMA(av[i][0], bq[d][j][0], acc[i][j]);
+                        bq[d][j][0] = *(const f32x4 *)(wb + (DB - 1) * wstep + j * 2048);
+                        bq[d][j][1] = *(const f32x4 *)(wb + (DB - 1) * wstep + j * 2048 + 1024);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                    // the weights of the next slab are loaded into a second register set before the MFMAs of this one
+                    f32x4 nb[NT][2];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        nb[j][0] = *(const f32x4 *)(wb + j * 2048);
+                        nb[j][1] = *(const f32x4 *)(wb + j * 2048 + 1024);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-                // the weights of the next slab are loaded into a second register set before the MFMAs of this one
-                f32x4 nb[NT][2];
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    nb[j][0] = *(const f32x4 *)(wb + j * 2048);
-                    nb[j][1] = *(const f32x4 *)(wb + j * 2048 + 1024);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int j = 0; j < NT; ++j) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
+                        for (int i = 0; i < MT; ++i) acc[i][j] = BB_MFMA(av[i][1], bq[0][j][0], acc[i][j]);
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) acc[i][j] = BB_MFMA(av[i][1], bq[j][0], acc[i][j]);
+                        for (int i = 0; i < MT; ++i) acc[i][j] = BB_MFMA(av[i][0], bq[0][j][1], acc[i][j]);
+                    }
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) acc[i][j] = BB_MFMA(av[i][0], bq[j][1], acc[i][j]);
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) acc[i][j] = BB_MFMA(av[i][0], bq[0][j][0], acc[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) { bq[0][j][0] = nb[j][0]; bq[0][j][1] = nb[j][1]; }
                 }
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) acc[i][j] = BB_MFMA(av[i][0], bq[j][0], acc[i][j]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) { bq[j][0] = nb[j][0]; bq[j][1] = nb[j][1]; }
+                for (int i = 0; i < MT; ++i) { av[i][0] = na[i][0]; av[i][1] = na[i][1]; }
             }
-#pragma unroll
-            for (int i = 0; i < MT; ++i) { av[i][0] = na[i][0]; av[i][1] = na[i][1]; }
         }
         if (c + 1 < nchunks) stage_commit((c + 1) & 1);
         __syncthreads();
@@ -405,9 +413,11 @@ static int conv_nit(const ConvCfg &c, int ks, int stride) {
     return ceil_div(ih * iw * (conv_ck(stride) / 8), 256);
 }
 
-// Tile of a launch: [32 MT (4 / WN) pixels] x [32 NT WN channels].  The largest tile has the best operand reuse (per slab 4
-// fragment reads and 8 weight loads for 24 MFMAs) and wins as soon as every compute unit gets a work-group; below that the
-// smallest one spreads the launch over the chip (measured per layer shape and batch size, tools/conv_sweep.py).
+// Tile of a launch: [32 MT (4 / WN) pixels] x [32 NT WN channels].  Measured per layer shape and batch size
+// (tools/conv_sweep.py, 60x80 maps = 37.5 tiles of 128 pixels per image): the small tile (64 pixels x 128 channels, three
+// slabs of weights in flight, 152 registers = three work-groups per compute unit) wins up to ~500 tiles and for every 1x1
+// and stride-2 layer; from there the 128 x 128 tile, and the 128 x 256 tile (24 MFMAs per 4 fragment reads and 8 weight
+// loads, but two work-groups per compute unit and one slab in flight) only for launches of several rounds.
 // P2P_CONV_TILE="mt,nt,wn" forces one (experiments).
 static ConvCfg conv_cfg(int co, int ks, int stride, long tiles128) {
     static const ConvCfg cand256[] = {{2, 4, 2, 0}, {1, 4, 2, 0}, {2, 2, 2, 0}, {1, 2, 2, 0}};
@@ -415,9 +425,11 @@ static ConvCfg conv_cfg(int co, int ks, int stride, long tiles128) {
     static const ConvCfg cand64[] = {{1, 2, 1, 0}};
     const ConvCfg *cand = co % 256 == 0 ? cand256 : (co % 128 == 0 ? cand128 : cand64);
     const int ncand = co % 256 == 0 ? 4 : (co % 128 == 0 ? 2 : 1);
-    ConvCfg best = cand[0];
-    if (co % 256 == 0 && tiles128 < 256) best = cand256[3];
-    if (co % 256 != 0 && co % 128 == 0 && tiles128 < 512) best = cand128[1];
+    ConvCfg best = cand[ncand - 1];
+    if (ks == 3 && stride == 1) {
+        if (co % 256 == 0 && tiles128 >= 512) best = tiles128 >= 1024 ? cand256[0] : cand256[2];
+        if (co % 256 != 0 && co % 128 == 0 && tiles128 >= 1024) best = cand128[0];
+    }
     if (const char *e = getenv("P2P_CONV_TILE")) {
         int mt = 0, nt = 0, wn = 0;
         if (sscanf(e, "%d,%d,%d", &mt, &nt, &wn) == 3)
@@ -444,7 +456,7 @@ extern "C" int p2p_conv_create(const float *weight, const p2p_bn_params *bn, int
                 "p2p_conv_create: %dx%d stride %d, %d -> %d channels is outside the ResNet34 layers this library covers", ks, ks, stride, ci, co);
     P2P_REQUIRE(stride == 1 || co % 128 == 0, P2P_EUNSUPPORTED, "p2p_conv_create: stride 2 with %d output channels", co);
     const int ck = conv_ck(stride), nchunks = ci / ck, spc = ck / 16, nsl = ks * ks * spc, ntiles = co / 32;
-    const size_t wbytes = ((size_t)nchunks * nsl + 1) * ntiles * 2048;
+    const size_t wbytes = ((size_t)nchunks * nsl + 3) * ntiles * 2048;      // + the slabs of zeros the prefetch runs into
     std::vector<unsigned char> h(wbytes + 2 * (size_t)co * 4, 0);
     float *sc = (float *)(h.data() + wbytes), *sh = sc + co;
     std::vector<int> sw(co);
@@ -501,16 +513,16 @@ extern "C" void p2p_conv_destroy(p2p_conv *cv) {
     delete cv;
 }
 
-template <int MT, int NT, int WN, int NIT>
+template <int MT, int NT, int WN, int NIT, int DB>
 static int launch_conv(const ConvArgs &a, dim3 grid, size_t lds, hipStream_t stream) {
     static bool attr_set[64] = {false};
     int dev = 0;
     P2P_HIP_CHECK(hipGetDevice(&dev));
     if (dev >= 64 || !attr_set[dev]) {
-        P2P_HIP_CHECK(hipFuncSetAttribute((const void *)conv_kernel<MT, NT, WN, NIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        P2P_HIP_CHECK(hipFuncSetAttribute((const void *)conv_kernel<MT, NT, WN, NIT, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((conv_kernel<MT, NT, WN, NIT>), grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv_kernel<MT, NT, WN, NIT, DB>), grid, dim3(256), lds, stream, a);
     return check_launch("conv_kernel");
 }
 
@@ -534,13 +546,17 @@ extern "C" int p2p_conv_forward(const p2p_conv *cv, const float *x, const int *x
     const size_t lds = (size_t)2 * 2 * ((ih * iw * (a.ck * 2 + 16) + 15) & ~15);
     P2P_REQUIRE(lds <= 160 * 1024, P2P_EUNSUPPORTED, "p2p_conv_forward: staging tile of %zu bytes", lds);
     const dim3 grid(a.tiles_x * a.tiles_y * n, cv->co / (32 * c.nt * c.wn));
-    if (c.mt == 2 && c.nt == 4 && c.wn == 2 && c.nit <= 3) return launch_conv<2, 4, 2, 3>(a, grid, lds, stream);
-    if (c.mt == 1 && c.nt == 4 && c.wn == 2 && c.nit <= 3) return launch_conv<1, 4, 2, 3>(a, grid, lds, stream);
-    if (c.mt == 2 && c.nt == 2 && c.wn == 2 && c.nit <= 3) return launch_conv<2, 2, 2, 3>(a, grid, lds, stream);
-    if (c.mt == 2 && c.nt == 2 && c.wn == 2 && c.nit <= 5) return launch_conv<2, 2, 2, 5>(a, grid, lds, stream);
-    if (c.mt == 1 && c.nt == 2 && c.wn == 2 && c.nit <= 3) return launch_conv<1, 2, 2, 3>(a, grid, lds, stream);
-    if (c.mt == 1 && c.nt == 2 && c.wn == 2 && c.nit <= 5) return launch_conv<1, 2, 2, 5>(a, grid, lds, stream);
-    if (c.mt == 1 && c.nt == 2 && c.wn == 1 && c.nit <= 3) return launch_conv<1, 2, 1, 3>(a, grid, lds, stream);
+    const bool deep = cv->ks == 3;          // 18 or 9 slabs per chunk: three in flight; 1x1 convolutions have 2 or 1
+    if (c.mt == 2 && c.nt == 4 && c.wn == 2 && c.nit <= 3) return launch_conv<2, 4, 2, 3, 1>(a, grid, lds, stream);
+    if (c.mt == 1 && c.nt == 4 && c.wn == 2 && c.nit <= 3) return launch_conv<1, 4, 2, 3, 1>(a, grid, lds, stream);
+    if (c.mt == 2 && c.nt == 2 && c.wn == 2 && c.nit <= 3)
+        return deep ? launch_conv<2, 2, 2, 3, 3>(a, grid, lds, stream) : launch_conv<2, 2, 2, 3, 1>(a, grid, lds, stream);
+    if (c.mt == 2 && c.nt == 2 && c.wn == 2 && c.nit <= 5)
+        return deep ? launch_conv<2, 2, 2, 5, 3>(a, grid, lds, stream) : launch_conv<2, 2, 2, 5, 1>(a, grid, lds, stream);
+    if (c.mt == 1 && c.nt == 2 && c.wn == 2 && c.nit <= 3)
+        return deep ? launch_conv<1, 2, 2, 3, 3>(a, grid, lds, stream) : launch_conv<1, 2, 2, 3, 1>(a, grid, lds, stream);
+    if (c.mt == 1 && c.nt == 2 && c.wn == 1 && c.nit <= 3)
+        return deep ? launch_conv<1, 2, 1, 3, 3>(a, grid, lds, stream) : launch_conv<1, 2, 1, 3, 1>(a, grid, lds, stream);
     set_error("p2p_conv_forward: no kernel instance (%d,%d,%d) with %d staged pieces per thread", c.mt, c.nt, c.wn, c.nit);
     return P2P_EUNSUPPORTED;
 }

@@ -185,13 +185,8 @@ class Patch2Pix(nn.Module):
         return corr4d, delta4d
 
     def forward(self, im1, im2, ksize=1, return_feats=False):
-        if return_feats:
-            feat1s = self.extract.pyramid(im1)
-            feat2s = self.extract.pyramid(im2)
-            feat1, feat2 = feat1s[-1], feat2s[-1]
-        else:
-            feat1 = self.extract(im1, early_feat=True)
-            feat2 = self.extract(im2, early_feat=True)
+        feat1s, feat2s = self._pyramids(im1, im2)
+        feat1, feat2 = feat1s[-1], feat2s[-1]
         corr4d, delta4d = self.forward_coarse_match(feat1, feat2, ksize=ksize)
         if return_feats:
             return corr4d, delta4d, feat1s, feat2s
@@ -347,9 +342,17 @@ class Patch2Pix(nn.Module):
         ticket = self.coarse_async(feats1, feats2, ksize)
         return self.fine_from_ticket(ticket, ncn_thres, mutual, return_all, ptmax)
 
+    def _pyramids(self, im1, im2):
+        """The two pyramids; equally sized image batches go through the backbone as one batch (an image's pyramid does not
+        depend on its batch mates: tests/test_gpu_parity.py::test_backbone_batch_and_tile_independence)."""
+        if im1.shape == im2.shape and im1.is_cuda:
+            feats = self.extract.pyramid(torch.cat([im1, im2]))
+            n = im1.shape[0]
+            return [f[:n] for f in feats], [f[n:] for f in feats]
+        return self.extract.pyramid(im1), self.extract.pyramid(im2)
+
     def predict_fine(self, im1, im2, ksize=2, ncn_thres=0.0, mutual=True, return_all=False):
-        feats1 = self.extract.pyramid(im1)
-        feats2 = self.extract.pyramid(im2)
+        feats1, feats2 = self._pyramids(im1, im2)
         return self.predict_fine_from_feats(feats1, feats2, ksize, ncn_thres, mutual, return_all)
 
     def refine_matches(self, im1, im2, coarse_matches, io_thres):
@@ -361,8 +364,7 @@ class Patch2Pix(nn.Module):
         else:
             coarse_t = coarse_matches.to(self.device)
             coarse_matches = coarse_matches.cpu().data.numpy()
-        feats1 = self.extract.pyramid(im1)
-        feats2 = self.extract.pyramid(im2)
+        feats1, feats2 = self._pyramids(im1, im2)
         fine, fine_scores, _, _ = self._fine_chain(feats1, feats2, [coarse_t])
         refined = fine[0].cpu().data.numpy()
         scores = fine_scores[0].cpu().data.numpy()

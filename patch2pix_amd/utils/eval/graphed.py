@@ -1,4 +1,4 @@
-"""One image pair (or a batch of equally sized pairs) as ONE hipGraph launch: backbone (PyTorch-ROCm / MIOpen) ->
+"""One image pair (or a batch of equally sized pairs) as ONE hipGraph launch: pyramid producer (csrc/backbone.hip) ->
 coarse stage -> device-side filter_coarse -> both regressors, no host round trip in between.
 
 The reference runs a pair as ~700 kernel launches with two host synchronisations (filter_coarse on the host,
@@ -38,7 +38,12 @@ class GraphedMatcher:
 
     def _run(self):
         net = self.net
-        if self.with_backbone:
+        if self.with_backbone and self.in1.shape == self.in2.shape:
+            # both images through the backbone as one batch: half the launches, twice the work-groups per launch
+            feats = net.extract.pyramid(torch.cat([self.in1, self.in2]))
+            n = self.in1.shape[0]
+            f1, f2 = [f[:n] for f in feats], [f[n:] for f in feats]
+        elif self.with_backbone:
             f1, f2 = net.extract.pyramid(self.in1), net.extract.pyramid(self.in2)
         else:
             f1, f2 = self.in1, self.in2
