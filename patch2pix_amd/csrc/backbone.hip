@@ -302,7 +302,10 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(StemArgs a) {
 
     // the patch: rows iy0 ... iy0 + 20, columns ix0 ... ix0 + 68 (+ 3 columns of padding), three channels + a zero
     const size_t plane = (size_t)a.h * a.w;
-    for (int e = tid; e < ST_IH * ST_IW; e += 256) {
+    static_assert(ST_IH * ST_IW <= 6 * 256, "six staged pixels per thread");
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const int e0 = it * 256 + tid, e = min(e0, ST_IH * ST_IW - 1);
         const int py = e / ST_IW, px = e - py * ST_IW;
         const int iy = iy0 + py, ix = ix0 + px;
         const bool ok = iy >= 0 && iy < a.h && ix >= 0 && ix < a.w && px < 69;
@@ -311,8 +314,10 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(StemArgs a) {
         const float s = ok ? up : 0.f;
         const unsigned h01 = bb_pk(v0 * s, v1 * s), h2 = bb_pk(v2 * s, 0.f);
         const unsigned r01 = bb_pk(v0 * s - bb_lo(h01), v1 * s - bb_hi(h01)), r2 = bb_pk(v2 * s - bb_lo(h2), 0.f);
-        *(bu2 *)(xs + e * 8) = (bu2){h01, h2};
-        *(bu2 *)(xs + ST_PLB + e * 8) = (bu2){r01, r2};
+        if (e0 < ST_IH * ST_IW) {
+            *(bu2 *)(xs + e * 8) = (bu2){h01, h2};
+            *(bu2 *)(xs + ST_PLB + e * 8) = (bu2){r01, r2};
+        }
     }
     __syncthreads();
 
@@ -360,12 +365,15 @@ __global__ __launch_bounds__(256) void maxpool_nhwc_kernel(const float *__restri
     const int px0 = blockIdx.x * PL_TW, py = blockIdx.y;
     const int img = blockIdx.z / (c >> 6), c0 = (blockIdx.z % (c >> 6)) << 6;
     const float *xi = x + ((size_t)img * c + c0) * h * w;
-    for (int e = tid; e < 64 * 3 * 65; e += 256) {
-        const int ch = e / 195, rem = e - ch * 195, r = rem / 65, col = rem - r * 65;
+    // 49 loads per thread, issued seven at a time (clamped addresses, the store is what is conditional)
+#pragma unroll 7
+    for (int it = 0; it < 49; ++it) {
+        const int e = it * 256 + tid, ec = min(e, 64 * 3 * 65 - 1);
+        const int ch = ec / 195, rem = ec - ch * 195, r = rem / 65, col = rem - r * 65;
         const int iy = 2 * py - 1 + r, ix = 2 * px0 - 1 + col;
         const bool ok = iy >= 0 && iy < h && ix >= 0 && ix < w;
         const float v = xi[((size_t)ch * h + bb_clamp(iy, 0, h - 1)) * w + bb_clamp(ix, 0, w - 1)];
-        s[(ch * 3 + r) * PL_ROW + col] = ok ? v : -INFINITY;
+        if (e < 64 * 3 * 65) s[(ch * 3 + r) * PL_ROW + col] = ok ? v : -INFINITY;
     }
     __syncthreads();
     const int ch = tid & 63;

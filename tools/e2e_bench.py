@@ -87,16 +87,30 @@ def measure(net, H=480, W=640, pairs=4, reps=3, stream_pairs=160):
                               f"images on one loader thread; {st['proposals_per_pair']:.0f} proposals per pair (the model's own mutual matches)")
     except Exception as e:      # informational
         out["stages_error"] = repr(e)
-    im = torch.randn(2, 3, H, W, device=net.device)
-    with torch.no_grad():
-        for _ in range(3):
-            net.extract.pyramid(im)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(10):
-            net.extract.pyramid(im)
-        torch.cuda.synchronize()
-        out["backbone_ms_per_image"] = (time.perf_counter() - t0) / 20 * 1e3
+    def producer_ms(nb, reps=10):
+        im = torch.randn(nb, 3, H, W, device=net.device)
+        with torch.no_grad():
+            for _ in range(3):
+                net.extract.pyramid(im)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                net.extract.pyramid(im)
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / (reps * nb) * 1e3
+    out["backbone_ms_per_image"] = producer_ms(2)
+    out["backbone_ms_per_image_batch16"] = producer_ms(16)
+    prev = os.environ.get("P2P_BACKBONE")
+    try:
+        os.environ["P2P_BACKBONE"] = "miopen"
+        out["backbone_ms_per_image_batch16_miopen"] = producer_ms(16, reps=5)
+    finally:
+        if prev is None:
+            os.environ.pop("P2P_BACKBONE", None)
+        else:
+            os.environ["P2P_BACKBONE"] = prev
+    out["backbone"] = ("pyramid producer = HIP convolutions of csrc/backbone.hip (fp32-equivalent fp16x2); *_miopen = the same "
+                       "torch module through PyTorch-ROCm / MIOpen fp32")
     return out
 
 
