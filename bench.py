@@ -78,6 +78,7 @@ def parse():
     ap.add_argument("--pairs-per-step", type=int, default=None,
                     help="image pairs per step; their proposals share one regress launch (fills the 256 CUs)")
     ap.add_argument("--mode", choices=sorted(MODES), default=None, help="regressor arithmetic (default: library default)")
+    ap.add_argument("--depth", type=int, default=1, help="coarse stages enqueued ahead of the step whose proposals the host samples")
     ap.add_argument("--overlap", type=int, default=0,
                     help="1: coarse stage of step i+1 on a second stream beside the regress launch of step i; measured "
                          "neutral (444-446 vs 444-457 pairs/s: the regress launch stretches from 29.2 to 35.3 ms), so 0 is the default")
@@ -115,14 +116,28 @@ def oracle_pair(ckpt, pyr1, pyr2, ptmax, panc, seed, gpu_mid=None):
     return dict(all_rows=m, proposals=cm, mid=mid, mid_scores=mid_s, fine=fine, fine_scores=fine_s)
 
 
+def usable_cores():
+    """Logical cores this process may actually use: os.cpu_count() capped by the cgroup CPU quota (the GPU boxes expose
+    256 logical cores under a 16-core quota; thread teams wider than the quota get the whole process throttled)."""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(ckpt, pyr1, pyr2, cfg):
     """The CPU oracle (a port of the reference algorithm, oracle/p2p_oracle.py) on the host cores of this box, on a
     bounded sample of the same workload: one warm-up + 5 repetitions of one full pair (coarse stage + filter_coarse(ptmax)
-    + both regressors on all proposals), median.  32 threads: measured on the 2x64-core host, torch-CPU is fastest at 32
-    threads for these op sizes (8: 0.88 s, 32: 0.64 s, 128: 2.4 s for the coarse stage).  The port is conservative
+    + both regressors on all proposals), median.  min(32, cores the cgroup quota allows) threads: measured on the 2x64-core
+    host, torch-CPU is fastest at 32 threads for these op sizes (8: 0.88 s, 32: 0.64 s, 128: 2.4 s for the coarse stage);
+    more threads than the quota only get the process throttled.  The port is conservative
     for the comparison: its batched conv3d is faster than the reference's Python loop over conv3d slices; the
     unmodified reference itself cannot run on the GPU box (/root/reference is not there)."""
-    threads = min(32, os.cpu_count() or 1)
+    threads = min(32, usable_cores())
     torch.set_num_threads(threads)
     reps = 5 if cfg["H"] <= 480 else 1
     times = []
@@ -136,7 +151,8 @@ def cpu_baseline(ckpt, pyr1, pyr2, cfg):
     return {"value": 1.0 / t_pair, "unit": "pairs/s", "cores": threads, "kind": "port",
             "sample": f"1 warm-up + {reps} x one full {cfg['H']}x{cfg['W']} pair (coarse + filter ptmax={cfg['ptmax']} + mid/fine "
                       f"regressors on {cfg['ptmax'] * cfg['panc']} proposals), median {t_pair:.2f} s; torch-CPU fp32 port of the "
-                      f"reference algorithm (oracle/p2p_oracle.py), {threads} threads of {os.cpu_count()} logical cores, "
+                      f"reference algorithm (oracle/p2p_oracle.py), {threads} threads ({os.cpu_count()} logical cores, CPU quota "
+                      f"{usable_cores()}), "
                       f"torch {torch.__version__}"}
 
 
@@ -247,8 +263,8 @@ class Runner:
     """The benched loop over resident batches: `run(n)` = n steps, software-pipelined on one stream (the coarse stage of
     step i+1 is enqueued before the host samples the proposals of step i, so the GPU never waits for the host)."""
 
-    def __init__(self, net, batches, ptmax, overlap=False):
-        self.net, self.batches, self.ptmax = net, batches, ptmax
+    def __init__(self, net, batches, ptmax, overlap=False, depth=1):
+        self.net, self.batches, self.ptmax, self.depth = net, batches, ptmax, max(1, depth)
         self.coarse_stream = torch.cuda.Stream(device=net.device) if overlap else None
 
     def submit(self, i):
@@ -263,12 +279,11 @@ class Runner:
         return self.net.fine_from_ticket(ticket, ncn_thres=0.0, mutual=True, ptmax=self.ptmax)
 
     def run(self, nsteps):
-        out = []
-        ticket = self.submit(0)
+        out, tickets = [], [self.submit(j) for j in range(min(self.depth, nsteps))]
         for i in range(nsteps):
-            nxt = self.submit(i + 1) if i + 1 < nsteps else None
-            out.append(self.finish(ticket))
-            ticket = nxt
+            if i + self.depth < nsteps:
+                tickets.append(self.submit(i + self.depth))      # `depth` coarse stages enqueued ahead of the step being finished
+            out.append(self.finish(tickets.pop(0)))
         return out
 
 
@@ -425,8 +440,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    # host side of a rank is one Python thread plus small torch-CPU ops: keep N ranks from oversubscribing the host
-    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // max(world, 1))))
+    # host side of a rank is one Python thread plus small torch-CPU ops: keep N ranks from oversubscribing the host, and
+    # every thread team well inside the CPU quota (a team as wide as the quota, spinning after a parallel region, gets the
+    # whole process throttled for the rest of the scheduler period: one such stall costs a 20-step run 7 %)
+    torch.set_num_threads(max(1, min(8, usable_cores() // 2 // max(world, 1))))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -459,7 +476,7 @@ def main():
     # a few distinct synthetic batches per rank, resident in HBM before the clock starts
     cpu_pairs, batches = resident_batches(cfg, rank, dev, 2)
     np.random.seed(1234 + rank)
-    runner = Runner(net, batches, PTMAX, overlap=bool(args.overlap))
+    runner = Runner(net, batches, PTMAX, overlap=bool(args.overlap), depth=args.depth)
     run = runner.run
 
     def barrier():

@@ -12,7 +12,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-[ -f $ROOT/profiles/regress_traffic.json ] && cp $ROOT/profiles/regress_traffic.json $OUT/regress_traffic.json
+[ -f $ROOT/profiles/regress_traffic.json ] && [ ! -f $OUT/regress_traffic.json ] && cp $ROOT/profiles/regress_traffic.json $OUT/regress_traffic.json      # (a second call of one visit keeps the first one's records)
 # P2P_CONFIG=E profiles BASELINE configs[4] (960x1280, 2 pairs x 6400 proposals per step); files are tagged TAG_E_<mode>_*
 CFG=${P2P_CONFIG:-A}
 B="--no-cpu-baseline --no-parity --no-other-modes --no-e2e --no-other-configs --config $CFG"

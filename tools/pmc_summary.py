@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Summarise rocprofv3 --pmc result databases (one per counter group) into text + the regress traffic json.
-usage: python tools/pmc_summary.py OUT_TXT OUT_JSON MODE db1 db2 ...
+usage: python tools/pmc_summary.py OUT_TXT OUT_JSON MODE db1 db2 ...   (or: ... MODE OUT_TXT to rebuild the json record from the text)
 OUT_JSON is keyed by regressor mode ({"bf16x3": {...}, "f32": {...}}); an existing file is updated.  Every record carries
 the hash of the kernel sources it was measured with; bench.py reports `roofline.traffic` only when it matches."""
 import json
@@ -9,8 +9,25 @@ import sqlite3
 import sys
 
 
+def rows_from_txt(path):
+    """The per-kernel averages of a summary written by this script (profiles/*_pmc.txt) back into {kernel: {counter: (n, avg, ns)}}."""
+    rows, cur = {}, None
+    for line in open(path):
+        if line.startswith("#") or not line.strip():
+            continue
+        if not line.startswith(" "):
+            cur = rows.setdefault(line.strip(), {})
+        else:
+            name, n, avg, dur = line.split()[0], line.split("n=")[1].split("avg=")[0], line.split("avg=")[1].split()[0], line.split("avg_duration_ns=")[1]
+            cur[name] = (int(n), float(avg), float(dur))
+    return rows
+
+
 def main(out_txt, out_json, mode, dbs):
     rows = {}
+    if len(dbs) == 1 and dbs[0].endswith(".txt"):      # re-derive the json record from a committed summary (same numbers)
+        rows = rows_from_txt(dbs[0])
+        dbs = []
     for path in dbs:
         c = sqlite3.connect(path)
         q = ("select kernel_name, counter_name, count(*), avg(value), avg(end-start) from counters_collection "
@@ -25,7 +42,8 @@ def main(out_txt, out_json, mode, dbs):
             lines.append(k)
             for cn, (n, val, dur) in sorted(v.items()):
                 lines.append(f"    {cn:32s} n={n:4d} avg={val:.5g} avg_duration_ns={dur:.0f}")
-    open(out_txt, "w").write("\n".join(lines) + "\n")
+    if dbs:
+        open(out_txt, "w").write("\n".join(lines) + "\n")
     for k, rg in rows.items():
         if "regress" in k and "FETCH_SIZE" in rg and "GRBM_GUI_ACTIVE" in rg:
             fetch = rg["FETCH_SIZE"][1] * 1024 * 2
