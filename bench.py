@@ -78,7 +78,10 @@ def parse():
     ap.add_argument("--pairs-per-step", type=int, default=None,
                     help="image pairs per step; their proposals share one regress launch (fills the 256 CUs)")
     ap.add_argument("--mode", choices=sorted(MODES), default=None, help="regressor arithmetic (default: library default)")
-    ap.add_argument("--depth", type=int, default=1, help="coarse stages enqueued ahead of the step whose proposals the host samples")
+    ap.add_argument("--depth", type=int, default=2,
+                    help="coarse stages enqueued ahead of the step whose proposals the host samples (2: a host-side hiccup of a "
+                         "few ms -- shared test boxes have them, profiles/r03_host_effects.txt -- does not idle the GPU; "
+                         "no difference on a quiet host)")
     ap.add_argument("--overlap", type=int, default=0,
                     help="1: coarse stage of step i+1 on a second stream beside the regress launch of step i; measured "
                          "neutral (444-446 vs 444-457 pairs/s: the regress launch stretches from 29.2 to 35.3 ms), so 0 is the default")
@@ -385,7 +388,7 @@ def stream_mode(args, net, cfg, mode, rank, world, dev, dist):
 
     with torch.no_grad():
         t_spin = time.perf_counter()
-        while time.perf_counter() - t_spin < 1.5:                      # clocks / allocator / page cache (see main)
+        while time.perf_counter() - t_spin < float(os.environ.get("P2P_BENCH_SPINUP", "1.5")):                      # clocks / allocator / page cache (see main)
             run_pair_stream(2 * B, 0, 1, B, submit, finish, exchange=False)
             torch.cuda.synchronize()
         barrier()
@@ -446,6 +449,11 @@ def main():
     torch.set_num_threads(max(1, min(8, usable_cores() // 2 // max(world, 1))))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # the process that drives a GPU belongs on the GPU's socket (utils/host.py; profiles/r03_host_effects.txt)
+    pinned_cpus = None
+    if os.environ.get("P2P_NUMA_PIN", "1") != "0":
+        from patch2pix_amd.utils.host import pin_process_to_gpu
+        pinned_cpus = pin_process_to_gpu(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -505,7 +513,7 @@ def main():
         # untimed spin-up: a fresh box needs ~1 s of work before clocks / allocator / page cache settle
         # (the first process on a cold box otherwise measures ~30 % low), then the W warm-up steps
         t_spin = time.perf_counter()
-        while time.perf_counter() - t_spin < 1.5:
+        while time.perf_counter() - t_spin < float(os.environ.get("P2P_BENCH_SPINUP", "1.5")):
             run(2)
             torch.cuda.synchronize()
         run(args.warmup)
@@ -535,6 +543,9 @@ def main():
                              "note": "compulsory bytes of the whole path per pair (SURVEY 8d) x pairs/s per GPU; the path "
                                      "is MFMA-bound (4300 flop/B), so this fraction is << 1 by construction"},
             "per_gpu_pairs_per_s": value / world,
+            "host": {"threads_pinned_to_gpu_local_cpus": len(pinned_cpus) if pinned_cpus else 0,
+                     "torch_cpu_threads": torch.get_num_threads(), "usable_cores": usable_cores(),
+                     "coarse_stages_enqueued_ahead": args.depth},
         }
     # ---- outside the timed region (single-GPU runs only) ----
     if rank == 0 and world == 1:

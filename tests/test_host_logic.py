@@ -84,3 +84,12 @@ def test_filter_coarse_property_based():
             assert keys == sorted(keys)
 
     check()
+
+
+def test_gpu_local_cpu_list_parsing_and_no_gpu_behaviour():
+    """utils/host.py: sysfs cpulist syntax; without a GPU (here) nothing is pinned and nothing raises."""
+    from patch2pix_amd.utils import host
+    assert host._parse_cpulist("64-67,192,194-195\n") == {64, 65, 66, 67, 192, 194, 195}
+    assert host._parse_cpulist("") == set()
+    if not torch.cuda.is_available():
+        assert host.gpu_local_cpus(0) == set() and host.pin_process_to_gpu(0) is None

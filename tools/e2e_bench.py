@@ -116,5 +116,7 @@ def measure(net, H=480, W=640, pairs=4, reps=3, stream_pairs=160):
 
 if __name__ == "__main__":
     import json
+    from patch2pix_amd.utils.host import pin_process_to_gpu
+    pin_process_to_gpu(0)
     torch.backends.cudnn.benchmark = True
     print(json.dumps(measure(model_helper.load_model(synthetic.make_checkpoint(0), lprint=lambda *a: None)), indent=1))
