@@ -29,7 +29,7 @@ def _load(job):
     return idx, t1, t2, np.array([tuple(s1) + tuple(s2)]), job
 
 
-_pin_pool = {}      # (shape) -> [[pinned tensor, event-or-None], ...] ring of staging buffers for the image batches
+_pin_pool = {}      # (device, shape) -> ring of [pinned tensor, event-or-None] staging buffers for the image batches
 
 
 def _upload(tensors, device):
@@ -39,7 +39,7 @@ def _upload(tensors, device):
     if torch.device(device).type != "cuda":            # host-logic tests drive the generator with a CPU stand-in of the net
         return normalise_pixels(torch.stack(tensors).to(device))
     shape = (len(tensors),) + tuple(tensors[0].shape)
-    ring = _pin_pool.setdefault(shape, {"slots": [], "turn": 0})
+    ring = _pin_pool.setdefault((str(torch.device(device)), shape), {"slots": [], "turn": 0})     # an event belongs to its device
     if len(ring["slots"]) < 4:
         ring["slots"].append([torch.empty(shape, dtype=tensors[0].dtype).pin_memory(), None])
     slot = ring["slots"][ring["turn"] % len(ring["slots"])]

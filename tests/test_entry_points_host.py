@@ -134,3 +134,28 @@ def test_stream_equals_per_pair_host_logic(tmp_path, batch, workers):
 
 def test_stream_handles_empty_input():
     assert list(estimate_matches_stream(FakeNet(), [])) == []
+
+
+def test_bounded_loader_map_keeps_order_and_bound():
+    """stream._bounded_map: results in input order, never more than `ahead` jobs submitted beyond what was consumed."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    from patch2pix_amd.utils.eval import stream
+    lock, state = threading.Lock(), {"submitted": 0, "consumed": 0, "worst": 0}
+
+    def work(j):
+        with lock:
+            state["submitted"] += 1
+            state["worst"] = max(state["worst"], state["submitted"] - state["consumed"])
+        return j * j
+
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        got = []
+        for v in stream._bounded_map(pool, work, range(40), ahead=5):
+            with lock:
+                state["consumed"] += 1
+            got.append(v)
+    assert got == [j * j for j in range(40)]
+    assert state["worst"] <= 5 + 1          # the look-ahead window (+ the job submitted as its result is handed out)
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        assert list(stream._bounded_map(pool, work, [], ahead=4)) == []
