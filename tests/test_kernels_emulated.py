@@ -462,3 +462,37 @@ def test_backbone_stem_pool_transpose_against_torch(n, h, w, emu):
     want = torch.nn.functional.max_pool2d(level1, 3, 2, 1)           # max-pool and transposition are exact
     assert torch.equal(pooled.permute(0, 3, 1, 2), want) and torch.equal(back, want)
     assert torch.equal(pmax, want.abs().amax(dim=(1, 2, 3)))
+
+
+def test_backbone_basic_block_chain_against_torch(emu):
+    """Two BasicBlocks the way networks/resnet.py composes the three kinds of call (reference resnet.py:26-60): a
+    down-sampling block (conv1 stride 2 + ReLU, 1x1 stride-2 projection of the skip without ReLU, conv2 + skip + ReLU)
+    followed by an identity block, each layer fed with the maximum its producer reported."""
+    from patch2pix_amd.networks.resnet import _Basic
+    torch.manual_seed(5)
+    blocks = [_Basic(64, 128, 2).eval(), _Basic(128, 128, 1).eval()]
+    for blk in blocks:
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.1)
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+    x = torch.relu(torch.randn(1, 64, 14, 18))
+    with torch.no_grad():
+        ref = x.double()
+        for blk in blocks:
+            ref = blk.double()(ref)
+        for blk in blocks:
+            blk.float()
+
+    def bn(b):
+        return [b.weight.data, b.bias.data, b.running_mean, b.running_var]
+    cur = x
+    for blk in blocks:
+        skip = cur
+        if blk.downsample is not None:
+            skip, _ = emu_lib.conv_bn(emu, blk.downsample[0].weight.data, bn(blk.downsample[1]), blk.downsample[0].stride[0], cur, None, relu=False)
+        y, ymax = emu_lib.conv_bn(emu, blk.conv1.weight.data, bn(blk.bn1), blk.conv1.stride[0], cur, None, relu=True)
+        assert torch.equal(ymax, y.abs().amax(dim=(1, 2, 3)))
+        cur, _ = emu_lib.conv_bn(emu, blk.conv2.weight.data, bn(blk.bn2), 1, y, skip, relu=True)
+    assert cur.shape == ref.shape
+    assert ((cur.double() - ref).abs().max() / ref.abs().max()).item() < 2 * BACKBONE_TOL
