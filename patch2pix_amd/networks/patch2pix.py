@@ -3,7 +3,8 @@
 Same constructor config, attributes (`device`, `upsample`, `psize`, `panc`, ...), method names,
 argument meaning and return layouts as the reference class, so callers such as
 utils/eval/model_helper.py (and image-matching-toolbox through it) work unchanged.  The ResNet
-backbone runs on PyTorch-ROCm; everything after the feature pyramid is HIP.  Inference only:
+backbone (networks/resnet.py) keeps its torch parameters and runs its convolutions through the same
+library; everything after the feature pyramid is HIP as well.  Inference only:
 `config.training=True` raises (training is out of scope).
 """
 import numpy as np

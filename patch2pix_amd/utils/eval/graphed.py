@@ -50,7 +50,7 @@ class GraphedMatcher:
         return net.predict_fine_device(f1, f2, ksize=self.ksize, ncn_thres=self.ncn_thres, mutual=self.mutual)
 
     def capture(self):
-        """Warm up on a side stream (kernel attributes, MIOpen algorithm search, workspaces), then record."""
+        """Warm up on a side stream (kernel attributes, packed weights, workspaces), then record."""
         side = torch.cuda.Stream(device=self.net.device)
         side.wait_stream(torch.cuda.current_stream(self.net.device))
         with torch.no_grad(), torch.cuda.stream(side):
