@@ -67,10 +67,31 @@ class ResNet34(nn.Module):
         state.pop("_hip_sig", None)
         return state
 
+    def _hip_signature(self, device):
+        """(device, identity, version counter and storage of every tensor the packed weights were made from): changes with
+        load_state_dict / in-place edits (version), .to() / .data assignment (storage) and replaced Parameter objects
+        (identity).  Walks the known structure through the modules' own dictionaries: the generic parameters() /
+        buffers() iterators cost a millisecond per call, more than launching the 36 kernels."""
+        sig = [str(device)]
+        pairs = [(self.conv1, self.bn1)]
+        for name, _, _, _ in _STAGES:
+            for blk in self._modules[name]._modules.values():
+                m = blk._modules
+                pairs += [(m["conv1"], m["bn1"]), (m["conv2"], m["bn2"])]
+                if m.get("downsample") is not None:
+                    d = m["downsample"]._modules
+                    pairs.append((d["0"], d["1"]))
+        for conv, bn in pairs:
+            for t in (conv._parameters["weight"], bn._parameters["weight"], bn._parameters["bias"],
+                      bn._buffers["running_mean"], bn._buffers["running_var"]):
+                sig.append((id(t), t._version, t.data_ptr()))
+            sig.append(conv.stride)
+        return tuple(sig)
+
     def _hip_trunk(self, device):
         """The packed convolutions of layer1..layer3 for `device`, re-packed when a parameter changed."""
         from .. import ops
-        sig = (str(device),) + tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
+        sig = self._hip_signature(device)
         if getattr(self, "_hip_sig", None) != sig:
             def pack(conv, bn):
                 return ops.ConvBN(conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.stride[0], device)

@@ -93,3 +93,31 @@ def test_gpu_local_cpu_list_parsing_and_no_gpu_behaviour():
     assert host._parse_cpulist("") == set()
     if not torch.cuda.is_available():
         assert host.gpu_local_cpus(0) == set() and host.pin_process_to_gpu(0) is None
+
+
+def test_backbone_pack_cache_signature_follows_the_module():
+    """networks/resnet.py: the packed device-side weights are re-made whenever the signature moves -- after
+    load_state_dict (version counters), .data assignment (storage), a replaced Parameter (identity), change_stride."""
+    import copy
+    from patch2pix_amd.networks import resnet
+    net = resnet.ResNet34()
+    net.change_stride("layer3")
+    s0 = net._hip_signature("cuda:0")
+    assert net._hip_signature("cuda:0") == s0 and net._hip_signature("cuda:1") != s0
+    net.load_state_dict(net.state_dict())
+    s1 = net._hip_signature("cuda:0")
+    assert s1 != s0
+    net.layer2[1].bn2.running_var.add_(1.0)
+    s2 = net._hip_signature("cuda:0")
+    assert s2 != s1
+    net.layer1[0].conv1.weight.data = net.layer1[0].conv1.weight.data.clone()
+    s3 = net._hip_signature("cuda:0")
+    assert s3 != s2
+    net.layer3[5].conv2.weight = torch.nn.Parameter(net.layer3[5].conv2.weight.detach().clone())
+    s4 = net._hip_signature("cuda:0")
+    assert s4 != s3
+    net.change_stride("layer2")
+    assert net._hip_signature("cuda:0") != s4
+    net._hip_trunk_cache, net._hip_sig = object(), s4          # the cache itself is not copied or pickled
+    twin = copy.deepcopy(net)
+    assert not hasattr(twin, "_hip_trunk_cache") and not hasattr(twin, "_hip_sig")

@@ -496,3 +496,28 @@ def test_backbone_basic_block_chain_against_torch(emu):
         cur, _ = emu_lib.conv_bn(emu, blk.conv2.weight.data, bn(blk.bn2), 1, y, skip, relu=True)
     assert cur.shape == ref.shape
     assert ((cur.double() - ref).abs().max() / ref.abs().max()).item() < 2 * BACKBONE_TOL
+
+
+@pytest.mark.parametrize("case", ["one_pixel", "thin", "zeros", "signed", "huge"])
+def test_backbone_convolution_edge_inputs(case, emu):
+    """Extents smaller than a tile, an all-zero image (its recorded maximum is 0), signed inputs (the scale comes from
+    max |x|) and magnitudes far outside fp16 (the power-of-two operand scale brings them back)."""
+    gen = torch.Generator().manual_seed(11)
+    ci, co = 64, 128
+    wt = torch.randn(co, ci, 3, 3, generator=gen) * 0.05
+    bn = _bn_params(co, gen)
+    shape = {"one_pixel": (1, ci, 1, 1), "thin": (2, ci, 3, 37)}.get(case, (1, ci, 6, 9))
+    x = torch.randn(shape, generator=gen)
+    if case == "zeros":
+        x.zero_()
+    elif case == "huge":
+        x = x.abs() * 3e20
+    elif case != "signed":
+        x = x.relu()
+    for stride in (1, 2):
+        ref = _bn_eval64(torch.nn.functional.conv2d(x.double(), wt.double(), None, stride, 1), bn).relu()
+        got, gmax = emu_lib.conv_bn(emu, wt, bn, stride, x, None, True)
+        assert got.shape == ref.shape and torch.isfinite(got).all()
+        scale = ref.abs().amax(dim=(1, 2, 3), keepdim=True).clamp_min(1e-30)
+        assert ((got.double() - ref).abs() / scale).max().item() < BACKBONE_TOL
+        assert torch.equal(gmax, got.abs().amax(dim=(1, 2, 3)))
