@@ -87,13 +87,22 @@ def _call_coarse(net, args, imq, imr):
 
 
 # ------------------------------------------------------------------------------------------ matching
+_decoders = None        # two threads: the second image of a pair is decoded while the first one is (PIL releases the GIL)
+
+
 def _load_pair(net, im1, im2, ksize, imsize):
     """Both images as [1,3,H,W] tensors on the device + the (1,4) factors back to original pixels."""
+    global _decoders
+    if _decoders is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _decoders = ThreadPoolExecutor(max_workers=2, thread_name_prefix="p2p-decode")
+    # PIL decode + bicubic resize on the host like the reference (load_im_flexible); the uint8 pixels go to the device and
+    # are normalised there (bit-identical, a quarter of the upload)
+    second = _decoders.submit(load_im_pixels, im2, ksize, net.upsample, imsize=imsize)
+    loaded = [load_im_pixels(im1, ksize, net.upsample, imsize=imsize), None]
+    loaded[1] = second.result()
     tensors, factors = [], ()
-    for im in (im1, im2):
-        # PIL decode + bicubic resize on the host like the reference (load_im_flexible); the uint8 pixels go to the device
-        # and are normalised there (bit-identical, a quarter of the upload)
-        pixels, scale_wh = load_im_pixels(im, ksize, net.upsample, imsize=imsize)
+    for pixels, scale_wh in loaded:
         tensors.append(normalise_pixels(pixels.unsqueeze(0).to(net.device)))
         factors += tuple(scale_wh)
     return tensors[0], tensors[1], np.array([factors])
