@@ -12,8 +12,8 @@ independent, so with N ranks every rank runs its own K steps (weak scaling) and 
 gathered once over RCCL inside the timed region.  Prints ONE JSON line on rank 0.
 
 The headline (`value`, `dtype`, `roofline`) is measured in the library's default arithmetic, which is
-fp32-equivalent (bf16x3: every fp32 operand as three bf16 planes = 24 significant bits, fp32 accumulation;
-see include/p2p_hip.h).  Outside the timed region rank 0 also (i) pushes one of the benched pairs -- through the
+fp32-equivalent (fp16x2: every fp32 operand, scaled by an exact power of two, as two fp16 planes to within 2^-24; three
+MFMA products per fp32 product, fp32 accumulation; see include/p2p_hip.h).  Outside the timed region rank 0 also (i) pushes one of the benched pairs -- through the
 same batched calls -- and the CPU oracle and reports the differences (`parity`), (ii) times the other
 arithmetic modes for a few steps (`other_modes`, informational), (iii) times BASELINE configs[4] for a few steps
 (`other_configs.E`: 960x1280, ptmax 800 x panc 8 -- GPU legs only), (iv) times the oracle on the host (`cpu_baseline`).
@@ -50,13 +50,7 @@ CONFIGS = {
 FLOP_PER_PROPOSAL_LEVEL = 2 * 64 * 512 * (518 * 9) + 2 * 64 * 512 * (512 * 9) + 2 * (512 * 512 + 512 * 256 + 256 * 5)
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0
-# bf16 kernels: matrix-core work ISSUED per proposal and level = 8 waves x (584 conv1 units + 576 conv2 units)
-# x (products x 2 m-tiles) x v_mfma_f32_32x32x16_bf16 (32768 flop each); + 0.1 % K padding
 MODES = {
-    "bf16x3": dict(kernel="regress_x3_kernel", products=6, peak=PEAK_BF16_MFMA_TFLOPS / 6.0,
-                   dtype="f32-equivalent: bf16x3 (every f32 operand = exact sum of 3 bf16 planes, 24 significant bits; "
-                         "6 bf16 MFMA products per f32 product, f32 accumulate)",
-                   peak_note="peak = 2500 TFLOP/s dense bf16 MFMA / 6 MFMA products per fp32 product"),
     "fp16x2": dict(kernel="regress_h2_kernel", products=3, peak=PEAK_BF16_MFMA_TFLOPS / 3.0,
                    dtype="f32-equivalent: fp16x2 (every f32 operand, scaled by an exact power of two, = sum of 2 fp16 planes to within "
                          "2^-24 of its magnitude; 3 fp16 MFMA products per f32 product, f32 accumulate)",

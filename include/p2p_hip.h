@@ -46,6 +46,10 @@ const char *p2p_last_error(void);
  *   w1 [3,16,1,3,3,3]  b1 [16]  w2 [3,1,16,3,3,3]  b2 [1]                                     */
 int p2p_ncn_create(const float *w1, const float *b1, const float *w2, const float *b2, p2p_ncn **out);
 void p2p_ncn_destroy(p2p_ncn *ncn);
+/* Tests and sweeps: force the work-group tile (ta, tb, tc) of the consensus kernel for launches with this handle (0, 0, 0 =
+ * automatic; ta = 0 with tb, tc > 0: only the march length is picked).  Results do not depend on the tile: every output
+ * cell sums its contributions in one fixed order.                                                                   */
+int p2p_ncn_set_tile(p2p_ncn *ncn, int ta, int tb, int tc);
 
 /* FeatRegressNet with the released configuration (conv_kers [3,3], conv_strs [2,1],
  * conv_dims [512,512], fc_dims [512,256], feat_comb 'pre', psize 16, feat_idx [0,1,2,3]) --
@@ -71,23 +75,19 @@ void p2p_regressor_destroy(p2p_regressor *reg);
 
 /* Arithmetic used for the two convolutions of a regressor (everything else is fp32 either way; the
  * reference computes them in fp32, networks/modules.py:76-87):
- *   P2P_REGRESS_F32    v_mfma_f32_32x32x2_f32, bit-identical to an fp32 fma chain;
- *   P2P_REGRESS_BF16X3 fp32-equivalent on the bf16 matrix cores: every fp32 operand is the exact sum of three
- *                      bf16 numbers (24 significant bits), six v_mfma_f32_32x32x16_bf16 per product (all terms
- *                      down to 2^-16 of the product; the rest is below fp32 round-off), fp32 accumulation.
- *                      As accurate as P2P_REGRESS_F32 against an fp64 evaluation, ceiling 2.65x higher;
- *   P2P_REGRESS_FP16X2 fp32-equivalent on the fp16 matrix cores: every fp32 operand, scaled by an exact power of two
- *                      into the normal range of fp16, is the sum of two fp16 numbers to within 2^-24 of its
+ *   P2P_REGRESS_FP16X2 (default) fp32-equivalent on the fp16 matrix cores: every fp32 operand, scaled by an exact power of
+ *                      two into the normal range of fp16, is the sum of two fp16 numbers to within 2^-24 of its
  *                      magnitude; three v_mfma_f32_32x32x16_f16 per product (the dropped term is <= 2^-24 of it),
  *                      fp32 accumulation; the scales are undone exactly.  As accurate as P2P_REGRESS_F32 against
- *                      an fp64 evaluation, half the matrix-core work of P2P_REGRESS_BF16X3;
+ *                      an fp64 evaluation at 5.3x its matrix-core ceiling;
+ *   P2P_REGRESS_F32    v_mfma_f32_32x32x2_f32, bit-identical to an fp32 fma chain;
  *   P2P_REGRESS_BF16X2 reduced precision, opt-in only: two bf16 per operand (16 significant bits), three
  *                      products; regressed coordinates within ~2.5e-4 px of an fp64 evaluation.
- * New handles start in the mode named by the environment variable P2P_REGRESS_MODE ("f32" | "fp16x2" |
- * "bf16x3" | "bf16x2"), else P2P_REGRESS_DEFAULT.                                               */
+ * New handles start in the mode named by the environment variable P2P_REGRESS_MODE ("f32" | "fp16x2" | "bf16x2", read
+ * when the handle is created), else P2P_REGRESS_DEFAULT.  Only the weight stream of the mode in use is packed and
+ * uploaded; p2p_regressor_set_mode builds another mode's on its first selection (host-side packing + one upload).   */
 #define P2P_REGRESS_F32     0
 #define P2P_REGRESS_BF16X2  1
-#define P2P_REGRESS_BF16X3  2
 #define P2P_REGRESS_FP16X2  3
 #define P2P_REGRESS_DEFAULT P2P_REGRESS_FP16X2
 int p2p_regressor_set_mode(p2p_regressor *reg, int mode);
@@ -191,32 +191,40 @@ typedef struct p2p_pyramid {
  *   proposals   [n,4] int64 (is_float == 0) or fp32 (is_float != 0), device
  *   matches1/probs1 [n,4]/[n] fp32 outputs of reg1 (may be NULL when reg2 != NULL)
  *   matches2/probs2 outputs of reg2 (required when reg2 != NULL)
- *   raw1/raw2   optional [n,5] raw regressor outputs (NULL to skip)                             */
+ *   raw1/raw2   optional [n,5] raw regressor outputs (NULL to skip)
+ *   workspace   p2p_regress_workspace_bytes(n) bytes of device memory, 128-byte aligned (scratch of the launch: the pooled
+ *               convolution features of every proposal wait there for the batched FC tail; contents are meaningless
+ *               outside the call)                                                             */
+size_t p2p_regress_workspace_bytes(int n);
 int p2p_regress(const p2p_regressor *reg1, const p2p_regressor *reg2,
                 const p2p_pyramid *im1, const p2p_pyramid *im2,
                 const void *proposals, int is_float, int n,
                 float *matches1, float *probs1, float *raw1,
-                float *matches2, float *probs2, float *raw2, p2p_stream_t stream);
+                float *matches2, float *probs2, float *raw2,
+                void *workspace, size_t workspace_bytes, p2p_stream_t stream);
 
 /* The same for `nitems` image pairs in one launch (the reference loops over the batch items of its
  * list arguments, patch2pix.py:192): im1/im2 are arrays of nitems pyramids, counts[i] (HOST array) the
  * number of proposals of item i; proposals and every output are the per-item arrays concatenated in
- * item order.  Filling the chip matters here: one proposal occupies one compute unit.            */
+ * item order.  Filling the chip matters here: one proposal occupies one compute unit.  workspace:
+ * p2p_regress_workspace_bytes(sum of counts).                                                   */
 int p2p_regress_batch(const p2p_regressor *reg1, const p2p_regressor *reg2, int nitems,
                       const p2p_pyramid *im1, const p2p_pyramid *im2, const int *counts,
                       const void *proposals, int is_float,
                       float *matches1, float *probs1, float *raw1,
-                      float *matches2, float *probs2, float *raw2, p2p_stream_t stream);
+                      float *matches2, float *probs2, float *raw2,
+                      void *workspace, size_t workspace_bytes, p2p_stream_t stream);
 
 /* The same with the proposal counts in DEVICE memory (e.g. written by p2p_filter_coarse_batch): every item owns
  * `stride` slots of the proposal and output arrays ([nitems*stride, ...]), of which the first dev_counts[i] are used;
  * the other slots' outputs are left untouched.  Nothing has to come back to the host between the coarse and the fine
- * stage.                                                                                                          */
+ * stage.  workspace: p2p_regress_workspace_bytes(nitems * stride).                                                 */
 int p2p_regress_batch_dev(const p2p_regressor *reg1, const p2p_regressor *reg2, int nitems,
                           const p2p_pyramid *im1, const p2p_pyramid *im2, const int *dev_counts, int stride,
                           const void *proposals, int is_float,
                           float *matches1, float *probs1, float *raw1,
-                          float *matches2, float *probs2, float *raw2, p2p_stream_t stream);
+                          float *matches2, float *probs2, float *raw2,
+                          void *workspace, size_t workspace_bytes, p2p_stream_t stream);
 
 /* ---- feature-pyramid producer (the convolutions of ResNet34 layer1..layer3) ------------------ */
 

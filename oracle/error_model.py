@@ -15,12 +15,14 @@ not from a hand-picked tolerance:
     bf16x3 products; measured fp32 errors stay below 10 % of the resulting bound, see `check`),
     errors of the inputs are carried through |W|-convolutions, the ratios of MutualMatching through their
     derivatives, max() through the maximum of the operand bounds;
-  * `ErrorModel.check(volume32)` asserts that an fp32 volume (the oracle's, the kernel's) lies within `E` of `Z` --
-    run on every use, so the model is validated against real data, not assumed;
+  * `ErrorModel.check(volume32)` asserts that an fp32 volume (the oracle's, the kernel's) lies within `CHECK_LIMIT` x `E`
+    of `Z` -- run on every use, so the model is validated against real data, not assumed.  Measured |error| / bound: 0.04-0.09
+    (oracle), <= 0.12 (HIP kernels); the limit is 0.25, so a kernel whose error doubles fails here;
   * a row is DECIDABLE when the fp64 winner beats every competitor by more than the sum of their bounds: any fp32
     evaluation within the bounds must then return that winner.  `assert_decidable_rows` requires exactly that of a
     match list; `differing_rows_are_near_ties` accepts a difference between two lists only where the two candidates are
-    closer in fp64 than their bounds.
+    closer in fp64 than `NEAR_TIE_TOL` (0.25) x the sum of their bounds: with both evaluations inside CHECK_LIMIT x E no
+    larger gap can flip an argmax (the worst accepted gap on the fixtures is 0.06).
 """
 import math
 
@@ -31,6 +33,8 @@ import torch.nn.functional as F
 from . import p2p_oracle as orc
 
 U = 2.0 ** -24
+CHECK_LIMIT = 0.25        # an fp32 evaluation must stay within this fraction of the forward bound (measured: <= 0.12)
+NEAR_TIE_TOL = 0.25       # a differing argmax is accepted when the fp64 gap is below this fraction of the two bounds
 
 
 def _eps(n, lam):
@@ -94,11 +98,12 @@ class ErrorModel:
         ey = e1 + e2.permute(2, 3, 0, 1) + U * y.abs()
         self.Z, self.E = _mm_err(y, ey)
 
-    def check(self, volume32, what="fp32 volume"):
-        """An fp32 evaluation must lie inside the bound; returns the worst |error| / bound ratio."""
+    def check(self, volume32, what="fp32 volume", limit=CHECK_LIMIT):
+        """An fp32 evaluation must lie well inside the bound (`limit` x E); returns the worst |error| / bound ratio."""
         err = (volume32.double().reshape(self.Z.shape) - self.Z).abs()
         ratio = float((err / self.E.clamp_min(1e-300)).max())
-        assert ratio <= 1.0, f"{what}: |error| exceeds the fp32 error model by {ratio:.2f}x -- the model (or the volume) is wrong"
+        assert ratio <= limit, (f"{what}: |error| reaches {ratio:.2f} of the fp32 error model (limit {limit}) -- the volume is less "
+                                f"accurate than an fp32 evaluation should be (or the model is wrong)")
         return ratio
 
     # ---- decidability of the two argmaxes per cell (extract_ncmatches.py:27-54)
@@ -156,12 +161,12 @@ def assert_decidable_rows(rows_got, model, upsample=8):
     return int(ok.sum()), int(rows_got.shape[0])
 
 
-def differing_rows_are_near_ties(rows_got, rows_ref, model, upsample=8):
+def differing_rows_are_near_ties(rows_got, rows_ref, model, upsample=8, tol=NEAR_TIE_TOL):
     """rows_*: [nB+nA,4] int64 (B->A rows first, then A->B, networks/patch2pix.py:351-355).  Returns (number of differing
     rows, worst fp64 gap / bound ratio); raises AssertionError on a difference the error model does not allow.
     A row can differ in two ways: another pooled cell won the softmax argmax (both candidates' final values must be
-    closer in fp64 than the sum of their bounds), or the same cell won but its relocalisation (the 4-D max-pool argmax,
-    modules.py:11-34) picked another of the k^4 positions (the two full-resolution correlations must be)."""
+    closer in fp64 than `tol` x the sum of their bounds), or the same cell won but its relocalisation (the 4-D max-pool
+    argmax, modules.py:11-34) picked another of the k^4 positions (the two full-resolution correlations must be)."""
     rows_got, rows_ref = torch.as_tensor(rows_got), torch.as_tensor(rows_ref)
     bad = torch.nonzero((rows_got != rows_ref).any(dim=1)).flatten()
     if bad.numel() == 0:
@@ -177,7 +182,8 @@ def differing_rows_are_near_ties(rows_got, rows_ref, model, upsample=8):
             pg, pr = (rows_got[r] - upsample // 2) // upsample, (rows_ref[r] - upsample // 2) // upsample   # (jA,iA,jB,iB)
             ig, ir = (pg[1], pg[0], pg[3], pg[2]), (pr[1], pr[0], pr[3], pr[2])
             gap, bound = float((model.C[ig] - model.C[ir]).abs()), float(model.EC[ig] + model.EC[ir])
-            assert gap <= bound, f"row {r}: relocalisation differs and the two positions are {gap:.2e} apart in fp64 (bound {bound:.2e})"
+            assert gap <= tol * bound, (f"row {r}: relocalisation differs and the two positions are {gap:.2e} apart in fp64 "
+                                        f"({tol} x bound = {tol * bound:.2e})")
             worst = max(worst, gap / bound)
     if bool((~same_cell).any()):
         keep = ~same_cell
@@ -190,7 +196,7 @@ def differing_rows_are_near_ties(rows_got, rows_ref, model, upsample=8):
         gap = (model.Z[ag, bg, cg, dg] - model.Z[ar, br, cr, dr]).abs()
         bound = model.E[ag, bg, cg, dg] + model.E[ar, br, cr, dr]
         ratio = gap / bound.clamp_min(1e-300)
-        assert bool((ratio <= 1.0).all()), (f"{int((ratio > 1).sum())} differing rows are not near-ties: fp64 gap up to "
-                                            f"{float(ratio.max()):.2f}x the fp32 error bound of the two candidates")
+        assert bool((ratio <= tol).all()), (f"{int((ratio > tol).sum())} differing rows are not near-ties: fp64 gap up to "
+                                            f"{float(ratio.max()):.2f}x the fp32 error bound of the two candidates (accepted: {tol})")
         worst = max(worst, float(ratio.max()))
     return int(bad.numel()), worst

@@ -462,16 +462,13 @@ int launch_absmax(const float *x, size_t n, size_t stride, int pairs, int *out, 
 // Tile of the fused kernel for a volume and batch: the B row in pieces of <= 60 columns; (TB, TC) = (5, 8) keeps two
 // work-groups per compute unit (78 KB of LDS each) and gives 7 + 22 well-balanced MFMA tiles per strip; the march along a is
 // split only until the launch has >= 1024 work-groups (two per compute unit, twice over).  Returns the number of work-groups.
-static long nc_fused_tile(NcFusedArgs &a, int pairs) {
+static long nc_fused_tile(NcFusedArgs &a, int pairs, const int *forced) {
     const int d0 = a.d0, d1 = a.d1, d2 = a.d2, d3 = a.d3;
     a.nd = ceil_div(d3, 60);
     a.td = ceil_div(d3, a.nd);
     a.P = (a.td + 4 + 1) & ~1;
     a.tb = 5; a.tc = 8; a.ta = 0;
-    if (const char *e = getenv("P2P_NCF_TILE")) {       // experiments: "ta,tb,tc" (ta = 0: pick)
-        int ta = 0, tb = 0, tc = 0;
-        if (sscanf(e, "%d,%d,%d", &ta, &tb, &tc) == 3 && tb > 0 && tc > 0) { a.tb = tb; a.tc = tc; a.ta = ta; }
-    }
+    if (forced && forced[1] > 0 && forced[2] > 0) { a.ta = forced[0]; a.tb = forced[1]; a.tc = forced[2]; }      // (ta = 0: pick)
     a.tb = std::min(a.tb, d1); a.tc = std::min(a.tc, d2);
     // kernel limits: a row of <= 64 columns per wave instruction, <= 3 input rows per wave and plane, <= 2 layer-1 tiles per wave
     while (a.tc > 1 && (a.tc + 4 > 12 || (a.tc + 2) * a.P > 512)) --a.tc;
@@ -485,19 +482,13 @@ static long nc_fused_tile(NcFusedArgs &a, int pairs) {
     return (long)a.na * a.nb * a.nc * a.nd * 2 * pairs;
 }
 
-// enough work-groups for the fused kernel to fill the chip?  (a single 480x640 pair is not: 128 work-groups of 4 waves)
-bool nc_fused_fills_chip(int pairs, int d0, int d1, int d2, int d3) {
-    NcFusedArgs a{};
-    a.d0 = d0; a.d1 = d1; a.d2 = d2; a.d3 = d3;
-    return nc_fused_tile(a, pairs) >= 1024;
-}
-
 int launch_nc_fused(const float *X, float *Y, float *Y2, size_t stride, int pairs, int d0, int d1, int d2, int d3,
-                    const unsigned char *w_dev, float b2, const int *xmax, size_t xmax_stride, hipStream_t stream) {
+                    const unsigned char *w_dev, float b2, const int *xmax, size_t xmax_stride, const int *forced_tile,
+                    hipStream_t stream) {
     NcFusedArgs a{};
     a.X = X; a.Y = Y; a.Y2 = Y2; a.stride = stride; a.d0 = d0; a.d1 = d1; a.d2 = d2; a.d3 = d3; a.w = w_dev; a.b2 = b2;
     a.xmax = xmax; a.xmax_stride = xmax_stride;
-    nc_fused_tile(a, pairs);
+    nc_fused_tile(a, pairs, forced_tile);
     const size_t lds = nc_fused_lds_bytes(a.tb, a.tc, a.P);
     P2P_REQUIRE(a.P <= 64 && lds <= 160 * 1024 && a.tc + 4 <= 12 && (a.tc + 2) * a.P <= 512, P2P_EUNSUPPORTED,
                 "consensus tile does not fit (P %d, tc %d, LDS %zu)", a.P, a.tc, lds);

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <vector>
 #include "../../include/p2p_hip.h"
 
 namespace p2p {
@@ -76,26 +77,26 @@ static inline int check_launch(const char *what) {
 
 // opaque handles -------------------------------------------------------------------------------
 struct p2p_ncn {
-    float *dev;        // one device allocation holding everything below
-    float *w1cat;      // [81][32]  layer-1 taps x (16 direct-branch + 16 transposed-branch) channels
-    float *b1cat;      // [32]
-    float *w2m;        // [32][db][dc][da][dd]  layer-2: channels 0-15 direct branch, 16-31 transposed branch
-    float b2;          // scalar bias of layer 2 (same for both branches)
-    unsigned char *wfused;   // both layers as fp16x2 MFMA fragments for the fused kernel (consensus.hip), own allocation
+    float b2;                // scalar bias of layer 2 (same for both branches)
+    unsigned char *wfused;   // both layers, both branches as fp16x2 MFMA fragments (consensus.hip), one device allocation
+    int tile[3];             // forced (ta, tb, tc) of the fused kernel, 0 = automatic (p2p_ncn_set_tile: tests and sweeps)
 };
 
 struct p2p_regressor {
-    float *dev;        // one device allocation
-    const float *wp1;  // conv1 weights, MFMA-fragment order [8 waves][585 chunks][2][64 lanes][4]
-    const float *wp2;  // conv2 weights,                    [8][576][2][64][4]
-    const float *ws1, *ws2;     // the same weights split into bf16 hi/lo planes in 32x32x16 fragment order
-    const float *wx1, *wx2;     // the same weights split into three bf16 planes (24 significant bits)
-    const float *wh1, *wh2;     // the same weights, scaled per output channel, split into two fp16 planes
-    const float *bn1s_h, *bn2s_h;   // folded BN scales times the inverse of those weight (and activation) scales
-    int mode;                   // P2P_REGRESS_F32 | P2P_REGRESS_BF16X2 | P2P_REGRESS_BF16X3 | P2P_REGRESS_FP16X2
+    float *dev;        // BatchNorm folds + FC layers (every mode)
+    float *dev_p, *dev_s, *dev_h;   // the convolution weights in the stream order of the f32 / bf16x2 / fp16x2 kernel; packed on
+                                    // the first selection of that mode (p2p_regressor_set_mode), null until then
+    std::vector<float> conv1_w, conv2_w, bn1s_host, bn2s_host;   // host copies the packings are built from
+    const float *wp1;  // f32: conv1 weights, MFMA-fragment order [8 waves][585 chunks][2][64 lanes][4]
+    const float *wp2;  //      conv2 weights,                    [8][576][2][64][4]
+    const float *ws1, *ws2;     // bf16x2: the same weights split into bf16 hi/lo planes in 32x32x16 fragment order
+    const float *wh1, *wh2;     // fp16x2: the same weights, scaled per output channel, split into two fp16 planes
+    const float *bn1s_h, *bn2s_h;   // fp16x2: folded BN scales times the inverse of those weight (and activation) scales
+    int mode;                   // P2P_REGRESS_F32 | P2P_REGRESS_BF16X2 | P2P_REGRESS_FP16X2
     const float *bn1s, *bn1b;   // folded BN scale/shift [512]
     const float *bn2s, *bn2b;   // [512]
     const float *fc1t, *fc1b, *bnf1s, *bnf1b;   // fc1 as [128][512][4]; [512]
     const float *fc2t, *fc2b, *bnf2s, *bnf2b;   // fc2 as [128][256][4]; [256]
     const float *fc3, *fc3b;                    // [5][256]; [5]
+    const float *fc1p, *fc2p;                   // fc1 / fc2 as B fragments of v_mfma_f32_16x16x4_f32: [k/16][n/16][lane 64][4]
 };

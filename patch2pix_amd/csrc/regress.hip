@@ -344,20 +344,98 @@ static void fold_bn(const p2p_bn_params &bn, int n, float *scale, float *shift) 
 
 using namespace p2p;
 
-// Arithmetic of the two convolutions: the environment variable P2P_REGRESS_MODE ("f32" | "fp16x2" | "bf16x3" | "bf16x2")
-// picks the default for newly created regressors; p2p_regressor_set_mode overrides it per handle.
+// Arithmetic of the two convolutions: the environment variable P2P_REGRESS_MODE ("f32" | "fp16x2" | "bf16x2") picks the
+// mode newly created regressors start in (read at creation, nothing is cached); p2p_regressor_set_mode overrides it per
+// handle.  Only the weight stream of the mode in use is packed and uploaded; another mode's is built on its first selection.
 static int default_regress_mode() {
     const char *e = std::getenv("P2P_REGRESS_MODE");
     if (e && std::strcmp(e, "f32") == 0) return P2P_REGRESS_F32;
     if (e && std::strcmp(e, "bf16x2") == 0) return P2P_REGRESS_BF16X2;
-    if (e && std::strcmp(e, "bf16x3") == 0) return P2P_REGRESS_BF16X3;
     if (e && std::strcmp(e, "fp16x2") == 0) return P2P_REGRESS_FP16X2;
     return P2P_REGRESS_DEFAULT;
 }
 
+static int upload(const std::vector<float> &h, float **dev, const char *what) {
+    *dev = nullptr;
+    P2P_HIP_CHECK(hipMalloc(dev, h.size() * sizeof(float)));
+    hipError_t e = hipMemcpy(*dev, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(*dev);
+        *dev = nullptr;
+        set_error("hipMemcpy of %s failed: %s", what, hipGetErrorString(e));
+        return P2P_EHIP;
+    }
+    return P2P_OK;
+}
+
+// pack + upload the convolution weights in the stream order of `mode`'s kernel (once per handle and mode)
+static int ensure_mode(p2p_regressor *r, int mode) {
+    auto al = [](size_t n) { return (n + 63) & ~size_t(63); };
+    const float *c1 = r->conv1_w.data(), *c2 = r->conv2_w.data();
+    if (mode == P2P_REGRESS_FP16X2 && !r->dev_h) {
+        const size_t o1 = 0, o2 = al(WH1_FLOATS), ob1 = o2 + al(WH2_FLOATS), ob2 = ob1 + 512;
+        std::vector<float> h(ob2 + 512, 0.f);
+        std::vector<int> t1(512), t2(512);
+        pack_h2_weights(c1, c2, &h[o1], &h[o2], t1.data(), t2.data());
+        // conv1 accumulates 2^12 (activations) x 2^t1[n] (weights) x the true sum, conv2 2^t2[n] x (the per-proposal scale of H,
+        // undone in the kernel) x the true sum: exact powers of two folded into the BatchNorm scales
+        for (int n = 0; n < 512; ++n) {
+            h[ob1 + n] = std::ldexp(r->bn1s_host[n], -12 - t1[n]);
+            h[ob2 + n] = std::ldexp(r->bn2s_host[n], -t2[n]);
+        }
+        const int st = upload(h, &r->dev_h, "the fp16x2 weight streams");
+        if (st != P2P_OK) return st;
+        r->wh1 = r->dev_h + o1; r->wh2 = r->dev_h + o2; r->bn1s_h = r->dev_h + ob1; r->bn2s_h = r->dev_h + ob2;
+    } else if (mode == P2P_REGRESS_BF16X2 && !r->dev_s) {
+        const size_t o2 = al(WS1_FLOATS);
+        std::vector<float> h(o2 + al(WS2_FLOATS), 0.f);
+        pack_split_weights(c1, c2, &h[0], &h[o2]);
+        const int st = upload(h, &r->dev_s, "the bf16x2 weight streams");
+        if (st != P2P_OK) return st;
+        r->ws1 = r->dev_s; r->ws2 = r->dev_s + o2;
+    } else if (mode == P2P_REGRESS_F32 && !r->dev_p) {
+        const size_t o_wp1 = 0, o_wp2 = al(WP1_FLOATS);
+        std::vector<float> h(o_wp2 + al(WP2_FLOATS), 0.f);
+        // conv1: Wp1[w][kc][u][lane][q] = W1[n = 64w+32u+(lane&31)][channel(kidx)][tap],
+        //        kidx = 8*(kc % 65) + 2q + (lane>>5), tap = kc / 65
+        for (int w = 0; w < 8; ++w)
+            for (int kc = 0; kc < K1_CHUNKS; ++kc) {
+                const int tap = kc / K1_CHUNKS_PER_TAP, kin = kc % K1_CHUNKS_PER_TAP;
+                for (int u = 0; u < 2; ++u)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int q = 0; q < 4; ++q) {
+                            const int n = 64 * w + 32 * u + (lane & 31);
+                            const int ch = conv1_channel_of(8 * kin + 2 * q + (lane >> 5));
+                            const size_t dst = o_wp1 + ((((size_t)w * (K1_CHUNKS + PF) + kc) * 2 + u) * 64 + lane) * 4 + q;
+                            h[dst] = (ch < 0) ? 0.f : c1[((size_t)n * 518 + ch) * 9 + tap];
+                        }
+            }
+        // conv2: kidx = 8*(kc % 64) + 2q + (lane>>5) is the input channel, tap = kc / 64
+        for (int w = 0; w < 8; ++w)
+            for (int kc = 0; kc < K2_CHUNKS; ++kc) {
+                const int tap = kc / K2_CHUNKS_PER_TAP, kin = kc % K2_CHUNKS_PER_TAP;
+                for (int u = 0; u < 2; ++u)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int q = 0; q < 4; ++q) {
+                            const int n = 64 * w + 32 * u + (lane & 31);
+                            const int ch = 8 * kin + 2 * q + (lane >> 5);
+                            const size_t dst = o_wp2 + ((((size_t)w * (K2_CHUNKS + PF) + kc) * 2 + u) * 64 + lane) * 4 + q;
+                            h[dst] = c2[((size_t)n * 512 + ch) * 9 + tap];
+                        }
+            }
+        const int st = upload(h, &r->dev_p, "the f32 weight streams");
+        if (st != P2P_OK) return st;
+        r->wp1 = r->dev_p + o_wp1; r->wp2 = r->dev_p + o_wp2;
+    }
+    return P2P_OK;
+}
+
 extern "C" int p2p_regressor_set_mode(p2p_regressor *reg, int mode) {
     P2P_REQUIRE(reg, P2P_EINVAL, "p2p_regressor_set_mode: null handle");
-    P2P_REQUIRE(mode == P2P_REGRESS_F32 || mode == P2P_REGRESS_BF16X2 || mode == P2P_REGRESS_BF16X3 || mode == P2P_REGRESS_FP16X2, P2P_EINVAL, "p2p_regressor_set_mode: unknown mode %d", mode);
+    P2P_REQUIRE(mode == P2P_REGRESS_F32 || mode == P2P_REGRESS_BF16X2 || mode == P2P_REGRESS_FP16X2, P2P_EINVAL,
+                "p2p_regressor_set_mode: unknown mode %d", mode);
+    const int st = ensure_mode(reg, mode);
+    if (st != P2P_OK) return st;
     reg->mode = mode;
     return P2P_OK;
 }
@@ -373,91 +451,53 @@ extern "C" int p2p_regressor_create(const p2p_regressor_params *p, p2p_regressor
                                  p->bnf2.weight, p->bnf2.bias, p->bnf2.running_mean, p->bnf2.running_var};
     for (const float *q : need) P2P_REQUIRE(q, P2P_EINVAL, "p2p_regressor_create: null weight pointer");
 
-    // layout of the single device allocation (floats)
+    // everything but the convolution weights (which are packed per arithmetic mode, ensure_mode): one device allocation
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += (n + 63) & ~size_t(63); return o; };
-    const size_t o_wp1 = take(WP1_FLOATS), o_wp2 = take(WP2_FLOATS);
-    const size_t o_ws1 = take(WS1_FLOATS), o_ws2 = take(WS2_FLOATS);
-    const size_t o_wx1 = take(WX1_FLOATS), o_wx2 = take(WX2_FLOATS);
-    const size_t o_wh1 = take(WH1_FLOATS), o_wh2 = take(WH2_FLOATS);
     const size_t o_bn1s = take(512), o_bn1b = take(512), o_bn2s = take(512), o_bn2b = take(512);
-    const size_t o_bn1sh = take(512), o_bn2sh = take(512);
     const size_t o_fc1t = take(512 * 512), o_fc1b = take(512), o_bnf1s = take(512), o_bnf1b = take(512);
     const size_t o_fc2t = take(256 * 512), o_fc2b = take(256), o_bnf2s = take(256), o_bnf2b = take(256);
     const size_t o_fc3 = take(5 * 256), o_fc3b = take(8);
+    const size_t o_fc1p = take(512 * 512), o_fc2p = take(256 * 512);
     std::vector<float> h(off, 0.f);
-
-    // conv1: Wp1[w][kc][u][lane][q] = W1[n = 64w+32u+(lane&31)][channel(kidx)][tap],
-    //        kidx = 8*(kc % 65) + 2q + (lane>>5), tap = kc / 65
-    for (int w = 0; w < 8; ++w)
-        for (int kc = 0; kc < K1_CHUNKS; ++kc) {
-            const int tap = kc / K1_CHUNKS_PER_TAP, kin = kc % K1_CHUNKS_PER_TAP;
-            for (int u = 0; u < 2; ++u)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int q = 0; q < 4; ++q) {
-                        const int n = 64 * w + 32 * u + (lane & 31);
-                        const int ch = conv1_channel_of(8 * kin + 2 * q + (lane >> 5));
-                        const size_t dst = o_wp1 + ((((size_t)w * (K1_CHUNKS + PF) + kc) * 2 + u) * 64 + lane) * 4 + q;
-                        h[dst] = (ch < 0) ? 0.f : p->conv1_w[((size_t)n * 518 + ch) * 9 + tap];
-                    }
-        }
-    // conv2: kidx = 8*(kc % 64) + 2q + (lane>>5) is the input channel, tap = kc / 64
-    for (int w = 0; w < 8; ++w)
-        for (int kc = 0; kc < K2_CHUNKS; ++kc) {
-            const int tap = kc / K2_CHUNKS_PER_TAP, kin = kc % K2_CHUNKS_PER_TAP;
-            for (int u = 0; u < 2; ++u)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int q = 0; q < 4; ++q) {
-                        const int n = 64 * w + 32 * u + (lane & 31);
-                        const int ch = 8 * kin + 2 * q + (lane >> 5);
-                        const size_t dst = o_wp2 + ((((size_t)w * (K2_CHUNKS + PF) + kc) * 2 + u) * 64 + lane) * 4 + q;
-                        h[dst] = p->conv2_w[((size_t)n * 512 + ch) * 9 + tap];
-                    }
-        }
-    pack_split_weights(p->conv1_w, p->conv2_w, &h[o_ws1], &h[o_ws2]);
-    std::vector<int> t1(512), t2(512);
-    pack_x3_weights(p->conv1_w, p->conv2_w, &h[o_wx1], &h[o_wx2], t1.data(), t2.data());
-    pack_h2_weights(p->conv1_w, p->conv2_w, &h[o_wh1], &h[o_wh2], t1.data(), t2.data());
     fold_bn(p->bn1, 512, &h[o_bn1s], &h[o_bn1b]);
     fold_bn(p->bn2, 512, &h[o_bn2s], &h[o_bn2b]);
-    // fp16x2: conv1 accumulates 2^12 (activations) x 2^t1[n] (weights) x the true sum, conv2 2^t2[n] x (the per-proposal
-    // scale of H, undone in the kernel) x the true sum: exact powers of two folded into the BatchNorm scales
-    for (int n = 0; n < 512; ++n) {
-        h[o_bn1sh + n] = std::ldexp(h[o_bn1s + n], -12 - t1[n]);
-        h[o_bn2sh + n] = std::ldexp(h[o_bn2s + n], -t2[n]);
-    }
     fold_bn(p->bnf1, 512, &h[o_bnf1s], &h[o_bnf1b]);
     fold_bn(p->bnf2, 256, &h[o_bnf2s], &h[o_bnf2b]);
-    // fc weights as [k/4][out][4] so that a wave reads 1 KiB contiguous per step
+    // fc weights as [k/4][out][4] so that a wave reads 1 KiB contiguous per step (per-proposal tail of the f32 / bf16x2 kernels)
     for (int o = 0; o < 512; ++o)
         for (int k = 0; k < 512; ++k) h[o_fc1t + ((size_t)(k / 4) * 512 + o) * 4 + (k & 3)] = p->fc1_w[(size_t)o * 512 + k];
     for (int o = 0; o < 256; ++o)
         for (int k = 0; k < 512; ++k) h[o_fc2t + ((size_t)(k / 4) * 256 + o) * 4 + (k & 3)] = p->fc2_w[(size_t)o * 512 + k];
+    pack_fc_mfma(p->fc1_w, 512, &h[o_fc1p]);      // the same two layers as MFMA fragments (batched tail of the fp16x2 kernel)
+    pack_fc_mfma(p->fc2_w, 256, &h[o_fc2p]);
     for (int i = 0; i < 512; ++i) h[o_fc1b + i] = p->fc1_b[i];
     for (int i = 0; i < 256; ++i) h[o_fc2b + i] = p->fc2_b[i];
     for (int i = 0; i < 5 * 256; ++i) h[o_fc3 + i] = p->fc3_w[i];
     for (int i = 0; i < 5; ++i) h[o_fc3b + i] = p->fc3_b[i];
 
     float *dev = nullptr;
-    P2P_HIP_CHECK(hipMalloc(&dev, off * sizeof(float)));
-    hipError_t e = hipMemcpy(dev, h.data(), off * sizeof(float), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        (void)hipFree(dev);
-        set_error("hipMemcpy of packed regressor weights failed: %s", hipGetErrorString(e));
-        return P2P_EHIP;
-    }
+    int st = upload(h, &dev, "the regressor's BatchNorm / FC parameters");
+    if (st != P2P_OK) return st;
     p2p_regressor *r = new p2p_regressor();
     r->dev = dev;
-    r->wp1 = dev + o_wp1; r->wp2 = dev + o_wp2;
-    r->ws1 = dev + o_ws1; r->ws2 = dev + o_ws2;
-    r->wx1 = dev + o_wx1; r->wx2 = dev + o_wx2;
-    r->wh1 = dev + o_wh1; r->wh2 = dev + o_wh2;
-    r->bn1s_h = dev + o_bn1sh; r->bn2s_h = dev + o_bn2sh;
-    r->mode = default_regress_mode();
+    r->dev_p = r->dev_s = r->dev_h = nullptr;
+    r->wp1 = r->wp2 = r->ws1 = r->ws2 = r->wh1 = r->wh2 = r->bn1s_h = r->bn2s_h = nullptr;
+    r->conv1_w.assign(p->conv1_w, p->conv1_w + (size_t)512 * 518 * 9);      // host copies: another mode's stream is packed on demand
+    r->conv2_w.assign(p->conv2_w, p->conv2_w + (size_t)512 * 512 * 9);
+    r->bn1s_host.assign(&h[o_bn1s], &h[o_bn1s] + 512);
+    r->bn2s_host.assign(&h[o_bn2s], &h[o_bn2s] + 512);
     r->bn1s = dev + o_bn1s; r->bn1b = dev + o_bn1b; r->bn2s = dev + o_bn2s; r->bn2b = dev + o_bn2b;
     r->fc1t = dev + o_fc1t; r->fc1b = dev + o_fc1b; r->bnf1s = dev + o_bnf1s; r->bnf1b = dev + o_bnf1b;
     r->fc2t = dev + o_fc2t; r->fc2b = dev + o_fc2b; r->bnf2s = dev + o_bnf2s; r->bnf2b = dev + o_bnf2b;
     r->fc3 = dev + o_fc3; r->fc3b = dev + o_fc3b;
+    r->fc1p = dev + o_fc1p; r->fc2p = dev + o_fc2p;
+    r->mode = default_regress_mode();
+    st = ensure_mode(r, r->mode);
+    if (st != P2P_OK) {
+        p2p_regressor_destroy(r);
+        return st;
+    }
     *out = r;
     return P2P_OK;
 }
@@ -465,14 +505,19 @@ extern "C" int p2p_regressor_create(const p2p_regressor_params *p, p2p_regressor
 extern "C" void p2p_regressor_destroy(p2p_regressor *reg) {
     if (!reg) return;
     (void)hipFree(reg->dev);
+    if (reg->dev_p) (void)hipFree(reg->dev_p);
+    if (reg->dev_s) (void)hipFree(reg->dev_s);
+    if (reg->dev_h) (void)hipFree(reg->dev_h);
     delete reg;
 }
 
 static RegDev to_dev(const p2p_regressor *r) {
     RegDev d;
-    d.wp1 = r->wp1; d.wp2 = r->wp2; d.ws1 = r->ws1; d.ws2 = r->ws2; d.wx1 = r->wx1; d.wx2 = r->wx2; d.wh1 = r->wh1; d.wh2 = r->wh2; d.bn1s_h = r->bn1s_h; d.bn2s_h = r->bn2s_h; d.bn1s = r->bn1s; d.bn1b = r->bn1b; d.bn2s = r->bn2s; d.bn2b = r->bn2b;
+    d.wp1 = r->wp1; d.wp2 = r->wp2; d.ws1 = r->ws1; d.ws2 = r->ws2; d.wh1 = r->wh1; d.wh2 = r->wh2;
+    d.bn1s_h = r->bn1s_h; d.bn2s_h = r->bn2s_h; d.bn1s = r->bn1s; d.bn1b = r->bn1b; d.bn2s = r->bn2s; d.bn2b = r->bn2b;
     d.fc1t = r->fc1t; d.fc1b = r->fc1b; d.bnf1s = r->bnf1s; d.bnf1b = r->bnf1b;
     d.fc2t = r->fc2t; d.fc2b = r->fc2b; d.bnf2s = r->bnf2s; d.bnf2b = r->bnf2b; d.fc3 = r->fc3; d.fc3b = r->fc3b;
+    d.fc1p = r->fc1p; d.fc2p = r->fc2p;
     return d;
 }
 
@@ -482,7 +527,8 @@ static int regress_batch_impl(const p2p_regressor *reg1, const p2p_regressor *re
                               const p2p_pyramid *im1, const p2p_pyramid *im2, const int *counts, const int *dev_counts,
                               const void *proposals, int is_float,
                               float *matches1, float *probs1, float *raw1,
-                              float *matches2, float *probs2, float *raw2, p2p_stream_t stream) {
+                              float *matches2, float *probs2, float *raw2, void *workspace, size_t workspace_bytes,
+                              p2p_stream_t stream) {
     P2P_REQUIRE(reg1 && im1 && im2 && counts, P2P_EINVAL, "p2p_regress: null argument");
     P2P_REQUIRE(nitems >= 0, P2P_EINVAL, "p2p_regress: negative item count");
     long long total = 0;
@@ -503,6 +549,18 @@ static int regress_batch_impl(const p2p_regressor *reg1, const p2p_regressor *re
                         im[s]->height, im[s]->width);
             for (int j = 0; j < 4; ++j) P2P_REQUIRE(im[s]->level[j], P2P_EINVAL, "p2p_regress: null pyramid level");
         }
+    }
+    const bool batched_fc = reg1->mode == P2P_REGRESS_FP16X2;
+    if (batched_fc) {
+        int most = 0;
+        for (int i0 = 0; i0 < nitems; i0 += MAXB) {
+            int n = 0;
+            for (int b = i0; b < nitems && b < i0 + MAXB; ++b) n += counts[b];
+            most = std::max(most, n);
+        }
+        P2P_REQUIRE(workspace && workspace_bytes >= regress_ws_floats((size_t)most) * sizeof(float) && ((uintptr_t)workspace & 127) == 0,
+                    P2P_ENOMEM, "p2p_regress: workspace of %zu bytes (p2p_regress_workspace_bytes, 128-byte aligned) needed, got %zu",
+                    regress_ws_floats((size_t)most) * sizeof(float), workspace ? workspace_bytes : (size_t)0);
     }
     int dev = 0;
     P2P_HIP_CHECK(hipGetDevice(&dev));
@@ -540,12 +598,11 @@ static int regress_batch_impl(const p2p_regressor *reg1, const p2p_regressor *re
         auto adv = [&](float *p, int cols) { return p ? p + (size_t)first_prop * cols : nullptr; };
         a.matches[0] = adv(matches1, 4); a.probs[0] = adv(probs1, 1); a.raw[0] = adv(raw1, 5);
         a.matches[1] = adv(matches2, 4); a.probs[1] = adv(probs2, 1); a.raw[1] = adv(raw2, 5);
+        a.ws = (float *)workspace;      // launches of one call are ordered on the stream: they may share the scratch
         if (n > 0) {
             int st;
             if (reg1->mode == P2P_REGRESS_FP16X2) {
                 st = launch_regress_h2(a, n, (hipStream_t)stream);
-            } else if (reg1->mode == P2P_REGRESS_BF16X3) {
-                st = launch_regress_x3(a, n, (hipStream_t)stream);
             } else if (reg1->mode == P2P_REGRESS_BF16X2) {
                 st = launch_regress_split(a, n, (hipStream_t)stream);
             } else {
@@ -563,28 +620,35 @@ extern "C" int p2p_regress_batch(const p2p_regressor *reg1, const p2p_regressor 
                                  const p2p_pyramid *im1, const p2p_pyramid *im2, const int *counts,
                                  const void *proposals, int is_float,
                                  float *matches1, float *probs1, float *raw1,
-                                 float *matches2, float *probs2, float *raw2, p2p_stream_t stream) {
+                                 float *matches2, float *probs2, float *raw2, void *workspace, size_t workspace_bytes,
+                                 p2p_stream_t stream) {
     return regress_batch_impl(reg1, reg2, nitems, im1, im2, counts, nullptr, proposals, is_float, matches1, probs1, raw1,
-                              matches2, probs2, raw2, stream);
+                              matches2, probs2, raw2, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t p2p_regress_workspace_bytes(int n) {
+    return n > 0 ? regress_ws_floats((size_t)n) * sizeof(float) : 0;
 }
 
 extern "C" int p2p_regress_batch_dev(const p2p_regressor *reg1, const p2p_regressor *reg2, int nitems,
                                      const p2p_pyramid *im1, const p2p_pyramid *im2, const int *dev_counts, int stride,
                                      const void *proposals, int is_float,
                                      float *matches1, float *probs1, float *raw1,
-                                     float *matches2, float *probs2, float *raw2, p2p_stream_t stream) {
+                                     float *matches2, float *probs2, float *raw2, void *workspace, size_t workspace_bytes,
+                                     p2p_stream_t stream) {
     P2P_REQUIRE(dev_counts && stride >= 1 && nitems >= 0 && nitems <= 4096, P2P_EINVAL, "p2p_regress_batch_dev: bad argument");
     std::vector<int> cap(nitems, stride);
     return regress_batch_impl(reg1, reg2, nitems, im1, im2, cap.data(), dev_counts, proposals, is_float, matches1, probs1,
-                              raw1, matches2, probs2, raw2, stream);
+                              raw1, matches2, probs2, raw2, workspace, workspace_bytes, stream);
 }
 
 extern "C" int p2p_regress(const p2p_regressor *reg1, const p2p_regressor *reg2,
                            const p2p_pyramid *im1, const p2p_pyramid *im2,
                            const void *proposals, int is_float, int n,
                            float *matches1, float *probs1, float *raw1,
-                           float *matches2, float *probs2, float *raw2, p2p_stream_t stream) {
+                           float *matches2, float *probs2, float *raw2, void *workspace, size_t workspace_bytes,
+                           p2p_stream_t stream) {
     P2P_REQUIRE(n >= 0, P2P_EINVAL, "p2p_regress: negative proposal count");
     return p2p_regress_batch(reg1, reg2, 1, im1, im2, &n, proposals, is_float, matches1, probs1, raw1, matches2, probs2,
-                             raw2, stream);
+                             raw2, workspace, workspace_bytes, stream);
 }

@@ -11,11 +11,11 @@ constexpr int MAXB = 16;                // image pairs per launch
 struct RegDev {
     const float *wp1, *wp2;             // f32 MFMA-fragment order (regress.hip)
     const float *ws1, *ws2;             // split-bf16 fragment order (regress_split.hip), viewed as 16-byte units
-    const float *wx1, *wx2;             // three-plane bf16 fragment order (regress_x3.hip)
     const float *wh1, *wh2;             // two-plane fp16 fragment order, per-channel power-of-two scales (regress_h2.hip)
     const float *bn1s, *bn1b, *bn2s, *bn2b;
     const float *bn1s_h, *bn2s_h;       // BN scales with the fp16 operand scales of regress_h2.hip folded in
     const float *fc1t, *fc1b, *bnf1s, *bnf1b, *fc2t, *fc2b, *bnf2s, *bnf2b, *fc3, *fc3b;
+    const float *fc1p, *fc2p;           // fc1 / fc2 in v_mfma_f32_16x16x4_f32 fragment order (fc_batch_parse)
 };
 
 struct ItemDev {
@@ -33,7 +33,13 @@ struct RegressArgs {
     int is_float, n, nlevels;
     RegDev reg[2];
     float *matches[2], *probs[2], *raw[2];
+    float *ws;                    // regress_ws_floats(n) floats of scratch (kernels with the batched FC tail; else unused)
 };
+
+// scratch of the kernels whose FC tail is batched over a work-group's proposals (regress_xn_impl.h): the pooled
+// convolution features V [level][n][512] and the un-truncated mid matches [n][4] the fine level starts from
+constexpr int FC_ROWS = 16;             // proposals per FC batch = rows of a v_mfma_f32_16x16x4_f32 tile
+static inline size_t regress_ws_floats(size_t n) { return ((2 * n * 512 + 31) & ~size_t(31)) + 4 * n + 32; }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -131,6 +137,156 @@ __device__ __forceinline__ void fc_tail_parse(const RegDev &R, const ItemDev &I,
     __syncthreads();
 }
 
+// ---- FC tail batched over the proposals of a (persistent) work-group ------------------------------------------------
+// A load that must see what another wave of this work-group stored to global memory earlier in the same launch (the vector
+// L1 is not guaranteed to reflect it): relaxed atomic load = cache-bypassing.
+__device__ __forceinline__ float load_coherent(const float *p) {
+    return __int_as_float(__atomic_load_n((const int *)p, __ATOMIC_RELAXED));
+}
+#define P2P_MFMA_F32_16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+constexpr int FCST1 = 512 + 4, FCST2 = 256 + 4;          // LDS row strides (floats): rows 16 bytes apart modulo the 256-byte bank row
+constexpr int FC_LDS_BYTES = FC_ROWS * (2 * FCST1 + FCST2) * 4;
+
+// FC 512->512->256->5 with folded BatchNorm1d + ReLU (networks/modules.py:89-99) and parse_regressor_out
+// (networks/patch2pix.py:138-155; psize 16, ptype 'center') for ALL proposals of this work-group at one level: proposal
+// r of the group is first + r * gridDim.x, its pooled convolution features V[512] wait in wsV (global scratch, written by
+// this work-group).  FC_ROWS proposals at a time are the 16 rows of v_mfma_f32_16x16x4_f32 tiles (exact fp32 products and
+// accumulation): the 1.5 MB of fc1 / fc2 weights are streamed once per 16 proposals instead of once per proposal (the
+// per-proposal tail took 5 % of the launch, all of it weight ingest), and a launch of a few hundred proposals -- one image
+// pair at evaluation time -- no longer pays three serial tails per compute unit.
+// K order inside a tile row: step (S, j) multiplies k = 16 S + 4 (lane >> 4) + j, so a lane's four A values of a super-step
+// S are one aligned 16-byte LDS read and its four B values one 16-byte global load (weights packed to match, pack_fc_mfma).
+// nextp: un-truncated matches of this level = the proposals of the next one (written when there is a next level).
+__device__ __forceinline__ void fc_batch_parse(const RegDev &R, const RegressArgs &args, int lvl, const float *wsV,
+                                               float *nextp, unsigned char *smb, int tid) {
+    P2P_OPAQUE(tid);      // keep the per-lane offsets inside the level loop (nothing lane-dependent is hoisted and spilled)
+    const int nwg = gridDim.x, first = blockIdx.x;
+    const int cnt = (args.n - first + nwg - 1) / nwg;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, kb = lane >> 4;
+    float *Vs = (float *)smb, *F1s = Vs + FC_ROWS * FCST1, *F2s = F1s + FC_ROWS * FCST1;
+#pragma unroll 1
+    for (int r0 = 0; r0 < cnt; r0 += FC_ROWS) {
+        {   // the rows' features: 16 x 512 floats, a thread moves 4 x 16 bytes of one row
+            const int row = tid >> 5, c4 = tid & 31;
+            const bool ok = r0 + row < cnt;
+            const float *src = wsV + (size_t)(first + (r0 + row) * nwg) * 512;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = 4 * (c4 + 32 * q);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok) v = (f32x4){load_coherent(src + col), load_coherent(src + col + 1), load_coherent(src + col + 2), load_coherent(src + col + 3)};
+                *(f32x4 *)(Vs + row * FCST1 + col) = v;
+            }
+        }
+        __syncthreads();
+        {   // fc1: this wave's 64 output channels = four 16-column tiles
+            f32x4 acc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float *w = R.fc1p + ((size_t)(wave * 4) * 64 + lane) * 4;       // [S 32][tile 32][lane 64][4]
+            const float *a = Vs + l15 * FCST1 + 4 * kb;
+#pragma unroll 2
+            for (int S = 0; S < 32; ++S) {
+                const f32x4 av = *(const f32x4 *)(a + 16 * S);
+                f32x4 bv[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bv[t] = *(const f32x4 *)(w + ((size_t)S * 32 + t) * 256);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = P2P_MFMA_F32_16(av[j], bv[t][j], acc[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int n = 16 * (4 * wave + t) + l15;
+                const float b = R.fc1b[n], s = R.bnf1s[n], sh = R.bnf1b[n];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) F1s[(4 * kb + r) * FCST1 + n] = fmaxf(fmaf(acc[t][r] + b, s, sh), 0.f);
+            }
+        }
+        __syncthreads();
+        {   // fc2: 32 output channels per wave
+            f32x4 acc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float *w = R.fc2p + ((size_t)(wave * 2) * 64 + lane) * 4;       // [S 32][tile 16][lane 64][4]
+            const float *a = F1s + l15 * FCST1 + 4 * kb;
+#pragma unroll 2
+            for (int S = 0; S < 32; ++S) {
+                const f32x4 av = *(const f32x4 *)(a + 16 * S);
+                f32x4 bv[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) bv[t] = *(const f32x4 *)(w + ((size_t)S * 16 + t) * 256);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[t] = P2P_MFMA_F32_16(av[j], bv[t][j], acc[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int n = 16 * (2 * wave + t) + l15;
+                const float b = R.fc2b[n], s = R.bnf2s[n], sh = R.bnf2b[n];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) F2s[(4 * kb + r) * FCST2 + n] = fmaxf(fmaf(acc[t][r] + b, s, sh), 0.f);
+            }
+        }
+        __syncthreads();
+        // fc3 (one fp32 fma chain in k order per output) + parse: wave w takes rows 2w and 2w + 1 (proposal and item are
+        // wave-uniform: scalar reads of the launch arguments), lane o < 5 = output o
+#pragma unroll 1
+        for (int rr = 0; rr < FC_ROWS / 8; ++rr) {
+            const int row = (FC_ROWS / 8) * wave + rr;
+            if (r0 + row >= cnt) break;
+            const int prop = first + (r0 + row) * nwg;
+            int it = 0;
+            while (it + 1 < args.nitems && prop >= args.start[it + 1]) ++it;
+            if (args.dev_counts && prop - args.start[it] >= args.dev_counts[it]) continue;      // empty slot: outputs untouched
+            const ItemDev &I = args.item[it];
+            if (lane < 5) {
+                const int o = lane;
+                const f32x4 *w = (const f32x4 *)(R.fc3 + o * 256);
+                const float *x = F2s + row * FCST2;
+                float s = 0.f;
+#pragma unroll 8
+                for (int k = 0; k < 64; ++k) {
+                    const f32x4 wv = w[k], xv = *(const f32x4 *)(x + 4 * k);
+                    s = fmaf(wv[0], xv[0], s);
+                    s = fmaf(wv[1], xv[1], s);
+                    s = fmaf(wv[2], xv[2], s);
+                    s = fmaf(wv[3], xv[3], s);
+                }
+                s += R.fc3b[o];
+                if (args.raw[lvl]) args.raw[lvl][(size_t)prop * 5 + o] = s;
+                if (o < 4) {
+                    float base;       // the proposal the offsets are relative to, un-truncated (patch2pix.py:145)
+                    if (lvl > 0) base = load_coherent(nextp + (size_t)prop * 4 + o);
+                    else if (args.is_float) base = ((const float *)args.proposals)[(size_t)prop * 4 + o];
+                    else base = (float)((const long long *)args.proposals)[(size_t)prop * 4 + o];
+                    const float off = 16.0f * tanhf(fmaxf(s, 0.f)) - 8.0f;
+                    const float hi = (float)((o == 0) ? I.W[0] : (o == 1) ? I.H[0] : (o == 2) ? I.W[1] : I.H[1]);
+                    const float fm = fminf(fmaxf(base + off, 0.f), hi);
+                    if (args.matches[lvl]) args.matches[lvl][(size_t)prop * 4 + o] = fm;
+                    if (lvl + 1 < args.nlevels) nextp[(size_t)prop * 4 + o] = fm;
+                } else {
+                    if (args.probs[lvl]) args.probs[lvl][prop] = 1.0f / (1.0f + expf(-s));
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// fc weight [N][512] (row-major, torch Linear) -> B fragments of v_mfma_f32_16x16x4_f32 in the K order of fc_batch_parse:
+// out[((S * (N / 16) + tile) * 64 + lane) * 4 + j] = W[16 tile + (lane & 15)][16 S + 4 (lane >> 4) + j]
+static inline void pack_fc_mfma(const float *w, int N, float *out) {
+    for (int S = 0; S < 32; ++S)
+        for (int t = 0; t < N / 16; ++t)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j)
+                    out[(((size_t)S * (N / 16) + t) * 64 + lane) * 4 + j] = w[(size_t)(16 * t + (lane & 15)) * 512 + 16 * S + 4 * (lane >> 4) + j];
+}
+
 // regress_split.hip
 constexpr int S1_SLABS = 4 + 9 * 2 * 16; // conv1: 4 slabs of level 0 (3 ch x 9 taps x 2 images, padded 54 -> 64), then per
                                         // (tap, image) 4 + 4 + 8 slabs of 16 channels of levels 1, 2, 3
@@ -144,15 +300,9 @@ void pack_split_weights(const float *conv1_w, const float *conv2_w, float *ws1, 
 int launch_regress_split(const RegressArgs &a, int n, hipStream_t stream);
 void split_conv1_index(int slab, int half, int j, int &ch, int &tap);   // K layout of conv1 shared by the bf16 kernels
 
-// regress_x3.hip: unit = (slab of 16 K, n-tile), three bf16 planes = 3 KiB per (wave, unit); stream order [slab][n-tile]
+// regress_h2.hip: unit = (slab of 16 K, n-tile), two fp16 planes = 2 KiB per (wave, unit); stream order [slab][n-tile]
 constexpr int XPF = 8;                   // units the weight prefetch may run past the end of a stream
-constexpr size_t WX1_FLOATS = (size_t)8 * (S1_UNITS + XPF) * 768;
-constexpr size_t WX2_FLOATS = (size_t)8 * (S2_UNITS + XPF) * 768;
-// t1 / t2 [512]: per-output-channel exponents the weights were scaled by (all zero for the bf16 planes)
-void pack_x3_weights(const float *conv1_w, const float *conv2_w, float *wx1, float *wx2, int *t1, int *t2);      // host
-int launch_regress_x3(const RegressArgs &a, int n, hipStream_t stream);
-
-// regress_h2.hip: the same streams with two fp16 planes = 2 KiB per (wave, unit)
+// t1 / t2 [512]: per-output-channel exponents the weights were scaled by
 constexpr size_t WH1_FLOATS = (size_t)8 * (S1_UNITS + XPF) * 512;
 constexpr size_t WH2_FLOATS = (size_t)8 * (S2_UNITS + XPF) * 512;
 void pack_h2_weights(const float *conv1_w, const float *conv2_w, float *wh1, float *wh2, int *t1, int *t2);      // host

@@ -42,26 +42,54 @@ constexpr int XSHARED = XRAW0 + 2 * 3 * 256 * 4;
 constexpr int XTMP2ST = 64 * 4 + 16, XTMP3ST = 128 * 4 + 16;      // fp32 copy of levels 2/3: [25][272] then [9][528]
 constexpr int XTMP3 = YNC2 * XTMP2ST, XTMPIMG = XTMP3 + YNC3 * XTMP3ST;
 constexpr int XA0ST = 64 * 4 + 16;
-constexpr int XTROWS = 28, XTROW = 64 * 4, XTW = XTROWS * XTROW;  // fold buffer of one wave
-constexpr int XTAB = XSHARED + 8 * XTW;
+// exclusive turns of the two waves of a SIMD on the matrix pipe (see XPP / the conv1 protocol below): 1 = on.
+// conv2 (MFMA-bound, 43 B/clk of weights) gains 3 % from them; conv1 -- bound by its weight ingest, which needs every wave's
+// loads in flight all the time -- loses 5 % of the launch to them (profiles/r04_ablation_log.txt), so its halves run free.
+#ifndef XF_TURNS1
+#define XF_TURNS1 0                     // conv1
+#endif
+#ifndef XF_TURNS2
+#define XF_TURNS2 1                     // conv2
+#endif
+constexpr int XTROW = 64 * 4;                                     // one fold-buffer row: 64 output channels of a wave, fp32
+#if XF_TURNS1
+constexpr int XTROWS = 28, XT2N = 4;      // level-2 buffer shared by waves w and w + 4 (their folds never overlap under the turn protocol)
+#else
+constexpr int XTROWS = 25, XT2N = 8;      // free-running waves: one buffer each, only the 25 rows that are read back
+#endif
+constexpr int XTW = XTROWS * XTROW;                               // level-2 fold buffer
+constexpr int XSHR = XT2N * XTW + 8 * 9 * XTROW;                  // + T3[8 waves][9 level-3 rows]
+constexpr int XTAB = XSHARED + XSHR;
 constexpr int XTABIMG = 17 * 17 * 8;
 constexpr int XSM_SCALE = XTAB + 2 * XTABIMG + 16;                // float [2][256]
 constexpr int XCONV1B = XSM_SCALE + 512 * 4;
-// conv2 phase: the three planes of one 128-channel chunk of H, [plane][65 px][128 ch bf16 (+16 B)] (row 64 = zeros
-// = padding), and the chunks still to come as fp32 [3][64 px][128 ch (+16 B)].
+// conv2 phase.  H = BN1(conv1), [64 px][512 ch], is conv2's A operand, walked in four K-chunks of 128 input channels; a
+// chunk's planes are [plane][65 px][128 ch 16-bit (+16 B)] (row 64 = zeros = the padding ring of the convolution).
 constexpr int HST = 128 * 2 + 16, HPL = 65 * HST;                 // 272, 17680
+#if XNPL == 2
+// two fp16 planes are as many bytes as fp32: ALL four chunks are written as planes by the BN1 pass (no conversion passes,
+// no work-group barriers inside conv2)
+constexpr int HCHUNK = XNPL * HPL;                                // 35360: planes of chunk c start at c * HCHUNK
+constexpr int XCONV2B = 4 * HCHUNK;
+#else
+// three bf16 planes of all of H would be 196 KB: the planes of ONE chunk, the chunks still to come wait as fp32
+// [3][64 px][128 ch (+16 B)] and are converted by the whole work-group between chunks
+constexpr int HCHUNK = 0;
 constexpr int XPARK = XNPL * HPL;
 constexpr int XPARKST = 128 * 4 + 16, XPARKCH = 64 * XPARKST;     // 528, 33792
 constexpr int XCONV2B = XPARK + 3 * XPARKCH;
-// both phases
-constexpr int XSM_V = (XCONV1B > XCONV2B) ? XCONV1B : XCONV2B;    // the persistent block starts above both phases' buffers
-constexpr int XSM_F1 = XSM_V + 512 * 4;
-constexpr int XSM_F2 = XSM_F1 + 512 * 4;
-constexpr int XSM_MISC = XSM_F2 + 256 * 4;
+#endif
+// both phases, then the FC batch of the level (fc_batch_parse) over the whole allocation
+constexpr int XSM_MISC = (XCONV1B > XCONV2B) ? XCONV1B : XCONV2B;  // [16] floats: 8-11 the proposal, 12-14 the fp16 scale reductions
+#ifdef P2P_X3_TIMING
+constexpr int XSM_BYTES = XSM_MISC + 16 * 4 + 8 * 16 * 4;
+#else
 constexpr int XSM_BYTES = XSM_MISC + 16 * 4;
-static_assert(2 * XTMPIMG <= 8 * XTW && 64 * XA0ST <= 8 * XTW, "the shared region is sized by the fold buffers");
+#endif
+static_assert(FC_LDS_BYTES <= XSM_MISC, "the FC batch stages its rows over the convolution buffers");
+static_assert(2 * XTMPIMG <= XSHR && 64 * XA0ST <= XSHR, "the shared region is sized by the fold buffers");
 static_assert(XIMG % 16 == 0 && YOFF2 % 16 == 0 && YOFF3 % 16 == 0 && YPL2 % 16 == 0 && YPL3 % 16 == 0 && XSHARED % 16 == 0 &&
-              XTAB % 16 == 0 && XSM_SCALE % 16 == 0 && HPL % 16 == 0 && XPARK % 16 == 0 && XCONV2B % 16 == 0,
+              XTAB % 16 == 0 && XSM_SCALE % 16 == 0 && HPL % 16 == 0 && HCHUNK % 16 == 0 && XCONV2B % 16 == 0,
               "16-byte alignment of ds_read_b128");
 static_assert(XSM_BYTES <= 160 * 1024, "LDS budget");
 
@@ -113,19 +141,30 @@ __device__ __forceinline__ void splitn(const f32x4 &xa, const f32x4 &xb, float s
     }
 }
 
+#ifndef XF_STAGGER
+#define XF_STAGGER 64                   // start-slot spacing of the work-groups in units of 64 cycles (0 = all start together)
+#endif
 #ifdef XF_PIN_W                         // timing experiment (wrong results): the weight stream never advances (always cache hits)
 #define XWADV(N)
 #else
 #define XWADV(N) wb += (N) * XUB;
 #endif
 #ifdef P2P_X3_TIMING                    // phase lengths in s_memtime ticks -> args.raw[0] (tools/x3_timing.py)
-#define XT_DECL unsigned xt_[14]; unsigned xt_last_;      /* 32-bit tick differences: wave-uniform, kept in SGPRs */
-#define XT_START xt_last_ = (unsigned)__builtin_amdgcn_s_memtime(); _Pragma("unroll") for (int i_ = 0; i_ < 14; ++i_) xt_[i_] = 0;
-#define XT(i) { const unsigned n_ = (unsigned)__builtin_amdgcn_s_memtime(); xt_[i] += n_ - xt_last_; xt_last_ = n_; }
+// per-wave counters in LDS (14 more live SGPRs spill): [wave][16] unsigned behind the misc block
+#define XTL_() ((unsigned *)(smb + XSM_MISC + 64) + wave * 16)
+#define XT_DECL
+#define XT_START { const unsigned n_ = (unsigned)__builtin_amdgcn_s_memtime(); if (P2P_LANE_ID() < 16) XTL_()[P2P_LANE_ID()] = (P2P_LANE_ID() == 15) ? n_ : 0u; }
+#define XT(i) { const unsigned n_ = (unsigned)__builtin_amdgcn_s_memtime(); if (P2P_LANE_ID() == 0) { unsigned *x_ = XTL_(); x_[i] += n_ - x_[15]; x_[15] = n_; } }
+#if P2P_X3_TIMING >= 2                  // also the three ranges inside a conv1 step (stamps inside the hot loop: spills)
+#define XTL(i) XT(i)
+#else
+#define XTL(i)
+#endif
 #else
 #define XT_DECL
 #define XT_START
 #define XT(i)
+#define XTL(i)
 #endif
 #if XN_FP16
 #define XMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(xe8, (a)), __builtin_bit_cast(xe8, (b)), (c), 0, 0, 0)
@@ -192,11 +231,14 @@ __device__ __forceinline__ void splitn(const f32x4 &xa, const f32x4 &xb, float s
       XHALF(acc00, acc01, S0, BC0, BC1) XPIPE(2) __builtin_amdgcn_sched_barrier(0);                                   \
       XLOADR(R1, N1) XLOADB(BN1, (AH) + 1) splitn(R0[0], R0[1], (SC0), S0);                          \
       XHALF(acc10, acc11, S1, BC0, BC1) XPIPE(2) __builtin_amdgcn_sched_barrier(0); }
-// Two consecutive slabs = four units.  On entry S0 holds the planes of the first slab's m-tile 0, R1 the raw
-// fragment of its m-tile 1 (XPRO), and B0/B1 the weights of its two units.  (N0,N1) = A addresses of the second
-// slab, (M0,M1) = of the slab after that.
-#define XSLAB2(N0, N1, M0, M1, SC0, SC1)                                                  \
-    { XSLAB(N0, N1, SC0, SC1, B0, B1, B2, B3, 2) XSLAB(M0, M1, SC0, SC1, B2, B3, B0, B1, 4) XWADV(4) }
+// Weights: a ring of EIGHT units = four slabs (B0 ... B7), every slab loads the two units of the slab THREE slabs ahead into
+// the buffers the previous slab just freed (AH = 6, 8, 10, 12 for the four slabs of a group, then the stream advances by 8
+// units).  conv1 streams 9.3 MB of weights per proposal against 141 k cycles of MFMA issue: it needs the full 64 B/clk of
+// the compute unit's vector-memory path, i.e. ~100 KB in flight per compute unit at the ~1500-cycle latency of a loaded L2
+// (a ring of four units, one slab ahead, left 4 KB per wave in flight: the cell range ran at a third of that rate).
+// Every range of conv1 is a whole number of groups (level 0: one, pixel range: one, cell range: three), so each starts at
+// ring position 0 with units 0-5 of its first group already in flight.
+#define XGROUP4(SL0, SL1, SL2, SL3) { SL0 SL1 SL2 SL3 XWADV(8) }
 // The last slab of such a run: nothing to read or split for a next slab.
 #define XSLABEND(SC1, BC0, BC1, BN0, BN1, AH)                                            \
     { XLOADB(BN0, AH) splitn(R1[0], R1[1], (SC1), S1);                                              \
@@ -214,13 +256,7 @@ __device__ __forceinline__ void splitn(const f32x4 &xa, const f32x4 &xb, float s
 #define XCSLAB(HALF, SC, SN, NP, NPL, BC0, BC1, BN0, BN1, AH)                             \
     { XLOADP(SN, NP, NPL) XLOADB(BN0, AH) XLOADB(BN1, (AH) + 1)                                                       \
       HALF(t0, t1, SC, BC0, BC1) XLPIPE(XNPL, XNM) __builtin_amdgcn_sched_barrier(0); }
-#ifndef XF_L3_32
 #define XF_L3_16 1
-#endif
-#ifdef XF_L3_16
-#if defined(XF_NO_PINGPONG) || defined(XF_CONV1_PAIR) || defined(XF_PPAR)
-#error "the 16-row level-3 path shares the T2 fold buffers between the halves of a SIMD pair: it needs the exclusive-turn protocol (add -DXF_L3_32 to these experiments)"
-#endif
 // Level 3 (9 cells per image) on 16-row tiles, v_mfma_f32_16x16x32_bf16 (A: lane l = row l & 15, K block
 // l >> 4; B: column l & 15; D: rows 4 * (l >> 4) + r, column l & 15).  One "pseudo-slab" = one K step of 32 channels
 // against two 16-column n-tiles = 12 MFMAs of 16 cycles and two weight units.
@@ -250,17 +286,15 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define X16SLAB(HALF, UA, UB, SC, LOADNEXT, BC0, BC1, BN0, BN1, AH)                       \
     { LOADNEXT XLOADB(BN0, AH) XLOADB(BN1, (AH) + 1)                                                                  \
       HALF(UA, UB, SC, BC0, BC1) __builtin_amdgcn_sched_barrier(0); }
-#endif
 // conv2: both m-tiles from the planes (AC0, AC1); (AN0, AN1) <- the next slab's (addresses NP0, NP1)
 // Two waves of a SIMD that both issue MFMAs back to back get ~57 % of the matrix pipe between them, one wave alone
 // 85 % (measured); so the two halves of the work-group take turns, two slabs (48 MFMAs) at a time: XPP() = the two
 // barriers that end a wave's turn and its partner's (a bare s_barrier: outstanding loads stay in flight).
-#ifdef XF_NO_PINGPONG
-#define XPP()
-#define XPB()
-#else
 #define XPB() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+#if XF_TURNS2
 #define XPP() __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
+#else
+#define XPP()
 #endif
 #ifdef XF_TURN4                         // experiment: four slabs per turn in conv2
 #define XPP2()
@@ -268,35 +302,21 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define XPP2() XPP()
 #endif
 // conv1 barrier protocol per step (see the loop): P0 before / P1 after the pixel range, C0 before / C1 after the cell
-// range, F after the fold.  Shipped: exclusive turns with staggered halves (waves 0-3: P | - | C | F, waves 4-7: - | C | F | P).
-#if defined(XF_NO_PINGPONG)
+// range, F after the fold.  Exclusive turns with staggered halves (waves 0-3: P | - | C | F, waves 4-7: - | C | F | P), or
+// (XF_TURNS1 = 0) no barriers at all: the halves keep their staggered order and run free.
 #define XSTAGGER(g) (g)
-#define XPB_P0(st)
-#define XPB_P1()
-#define XPB_C0(g)
-#define XPB_C1(g)
-#define XPB_F(st, g)
-#elif defined(XF_CONV1_PAIR)            // experiment: halves aligned range against range (P beside C): worse
-#define XSTAGGER(g) (g)
-#define XPB_P0(st)
-#define XPB_P1() XPB()
-#define XPB_C0(g)
-#define XPB_C1(g)
-#define XPB_F(st, g) XPB()
-#elif defined(XF_PPAR)                  // experiment: both halves run the pixel range together, then take turns on the cell range
-#define XSTAGGER(g) 0
-#define XPB_P0(st)
-#define XPB_P1() XPB()
-#define XPB_C0(g) if (g) XPB()
-#define XPB_C1(g) XPB()
-#define XPB_F(st, g) if (!(g)) XPB()
-#else
-#define XSTAGGER(g) (g)
+#if XF_TURNS1
 #define XPB_P0(st) if (st) XPB()
 #define XPB_P1() XPB()
 #define XPB_C0(g) XPB()
 #define XPB_C1(g) XPB()
 #define XPB_F(st, g) if (!(st)) XPB()
+#else
+#define XPB_P0(st)
+#define XPB_P1()
+#define XPB_C0(g)
+#define XPB_C1(g)
+#define XPB_F(st, g)
 #endif
 // (the MFMAs lead: the first ones issue as soon as the turn starts, the loads for later slabs follow in their shadow)
 #ifndef XH_BURST                        // one load behind every MFMA: 2-3 % faster than two bursts at the head (XH_BURST);
@@ -335,47 +355,63 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
       XHMFMAS(AC0, AC1, BC0, BC1)                                                                                     \
       XHPIPE() __builtin_amdgcn_sched_barrier(0); }
 
+// Persistent work-groups: the launch has min(n, compute units) of them (one fits a compute unit), work-group g owns the
+// proposals g, g + G, g + 2G, ...  Per level it runs the two convolutions of each of its proposals (pooled features V[512]
+// -> global scratch), then the FC tail of ALL of them as one batch (fc_batch_parse: weights streamed once per 16
+// proposals), whose regressed matches are the next level's proposals (patch2pix.py:259-272).
 __global__ __launch_bounds__(NT, 2) void XN_KERNEL(RegressArgs args) {
     P2P_DYN_SHARED(unsigned char, smb);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int prop = blockIdx.x;
-    int it = 0;
-    while (it + 1 < args.nitems && prop >= args.start[it + 1]) ++it;
-    if (args.dev_counts && prop - args.start[it] >= args.dev_counts[it]) return;      // empty slot (whole work-group)
-    const ItemDev &I = args.item[it];
+    const int nwg = gridDim.x;
 
     float *raw0 = (float *)(smb + XRAW0);
     float *scale = (float *)(smb + XSM_SCALE);
-    float *V = (float *)(smb + XSM_V);
-    float *F1 = (float *)(smb + XSM_F1);
-    float *F2 = (float *)(smb + XSM_F2);
     float *misc = (float *)(smb + XSM_MISC);
-
-    if (tid < 4) {
-        float v;
-        if (args.is_float) v = ((const float *)args.proposals)[prop * 4 + tid];
-        else v = (float)((const long long *)args.proposals)[prop * 4 + tid];
-        misc[8 + tid] = v;
-    }
-    __syncthreads();
+#if XF_STAGGER > 0
+    // De-synchronise the work-groups.  They all start together and take the same time per proposal, so their gather phases
+    // would coincide for the whole launch: 256 compute units x ~0.4 MB of 128-byte lines in one burst (the 36-byte rows of a
+    // level-1 window use a quarter of their lines) is bound by the HBM rate, while the memory idles for the rest of the period.
+    // Eight start slots XF_STAGGER x 64 cycles apart spread the bursts; a work-group keeps its offset for the whole launch.
+    for (int i = (int)((blockIdx.x >> 3) & 7); i > 0; --i) __builtin_amdgcn_s_sleep(XF_STAGGER);
+#endif
+    // scratch (re-derived from the launch arguments where it is used: two more live 64-bit pointers across the convolution
+    // phases spill): pooled features V [level][n][512], then the un-truncated matches of the previous level [n][4]
+#define XWS_V(lvl_) (args.ws + (size_t)(lvl_) * args.n * 512)
+#define XWS_NEXTP() (args.ws + ((2 * (size_t)args.n * 512 + 31) & ~(size_t)31))
 
 #pragma unroll 1
     for (int lvl = 0; lvl < args.nlevels; ++lvl) {
         const RegDev &R_ = args.reg[lvl];
+#pragma unroll 1
+      for (int prop = blockIdx.x; prop < args.n; prop += nwg) {
+        int it = 0;
+        while (it + 1 < args.nitems && prop >= args.start[it + 1]) ++it;
+        if (args.dev_counts && prop - args.start[it] >= args.dev_counts[it]) continue;      // empty slot (whole work-group)
+        const ItemDev &I = args.item[it];
+        if (tid < 4) {
+            float v;
+            if (lvl > 0) v = load_coherent(XWS_NEXTP() + (size_t)prop * 4 + tid);
+            else if (args.is_float) v = ((const float *)args.proposals)[(size_t)prop * 4 + tid];
+            else v = (float)((const long long *)args.proposals)[(size_t)prop * 4 + tid];
+#ifdef XF_SAME_PATCH                    // timing experiment (wrong results): every proposal gathers the same (cache-resident) patch
+            v = 100.f + 16.f * tid;
+#endif
+            misc[8 + tid] = v;
+        }
+#if XN_FP16
+        // per-level reductions behind the power-of-two operand scales: misc[12 + img] = smallest per-pixel L2 scale of the
+        // image (float bits, atomic min), misc[14] = largest |H| (float bits, atomic max)
+        if (tid >= 64 && tid < 67) ((int *)misc)[12 + tid - 64] = (tid < 66) ? 0x7f7fffff : 0;
+#endif
+        __syncthreads();
         // window origins (x, y) in image 1 / image 2 (networks/utils.py:8-19); scalars + selects, never an indexed array
         int moff = 8;                // opaque: the LDS address of misc is otherwise materialised before the loop and spilled
         P2P_OPAQUE(moff);
         const int xa = (int)misc[moff + 0] - 8, ya = (int)misc[moff + 1] - 8;
         const int xb = (int)misc[moff + 2] - 8, yb = (int)misc[moff + 3] - 8;
-#if XN_FP16
-        // per-level reductions behind the power-of-two operand scales: misc[12 + img] = smallest per-pixel L2 scale of the
-        // image (float bits, atomic min), misc[14] = largest |H| (float bits, atomic max)
-        if (tid < 3) ((int *)misc)[moff + 4 + tid] = (tid < 2) ? 0x7f7fffff : 0;
-#endif
 #define XX0(img_) ((img_) ? xb : xa)
 #define XY0(img_) ((img_) ? yb : ya)
-        __syncthreads();
         // opaque copy of the thread id for the staging phases (keeps their lane-only index math inside the level loop)
         int tidv = wave * 64 + P2P_LANE_ID();       // re-derived per level: not even the thread id is kept in a VGPR across it
         P2P_OPAQUE(tidv);
@@ -575,33 +611,31 @@ __global__ __launch_bounds__(NT, 2) void XN_KERNEL(RegressArgs args) {
 #define XZERO16(A_) { float z_ = 0.f; P2P_OPAQUE(z_); _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) A_[i_] = z_; }
         f32x16 acc00, acc01, acc10, acc11;
         XZERO16(acc00) XZERO16(acc01) XZERO16(acc10) XZERO16(acc11)
-        f32x4 B0[XNPL], B1[XNPL], B2[XNPL], B3[XNPL], S0[XNPL], S1[XNPL];
+        f32x4 B0[XNPL], B1[XNPL], B2[XNPL], B3[XNPL], B4[XNPL], B5[XNPL], B6[XNPL], B7[XNPL], S0[XNPL], S1[XNPL];
         const f32x16 zero16 = {0};
         {
             f32x4 R0[2], R1[2];
             const unsigned char *wb = (const unsigned char *)R_.XN_W1 + (size_t)wave * (S1_UNITS + XPF) * XUB;
             const unsigned wlane = (tidv & 63) * 16;
-            XLOADB(B0, 0) XLOADB(B1, 1)
+            XLOADB(B0, 0) XLOADB(B1, 1) XLOADB(B2, 2) XLOADB(B3, 3) XLOADB(B4, 4) XLOADB(B5, 5)
             {   // level 0 of both images: 4 slabs of the pre-scaled block
                 const unsigned char *p0 = smb + XSHARED + l31 * XA0ST + half * 32;
                 const unsigned char *p1 = p0 + 32 * XA0ST;
                 XPRO(p0, p1, 1.0f)
-                XSLAB2(p0 + 64, p1 + 64, p0 + 128, p1 + 128, 1.0f, 1.0f)
-                XSLAB2(p0 + 192, p1 + 192, p0, p1, 1.0f, 1.0f)
+                XGROUP4(XSLAB(p0 + 64, p1 + 64, 1.0f, 1.0f, B0, B1, B6, B7, 6),
+                        XSLAB(p0 + 128, p1 + 128, 1.0f, 1.0f, B2, B3, B0, B1, 8),
+                        XSLAB(p0 + 192, p1 + 192, 1.0f, 1.0f, B4, B5, B2, B3, 10),
+                        XSLAB(p0, p1, 1.0f, 1.0f, B6, B7, B4, B5, 12))
             }
             __syncthreads();   // the im2col block is dead: its region becomes the fold buffers
             XT(3)
             // this lane's row of the cell tile: level-2 cell l31 (rows >= 25 are never read back) and its level-3 parent
             const int c2y = (l31 < 25) ? l31 / 5 : 0, c2x = (l31 < 25) ? l31 - 5 * (l31 / 5) : 0;
-#ifdef XF_L3_16
-            // T2 (level-2 rows) is shared by wave w and w + 4: their folds never overlap under the turn protocol (G1's is
-            // over before e3, G0's runs between e3 and e4); T3 (9 level-3 rows) is private and written inside the C turn
-            float *Tw = (float *)(smb + XSHARED + (wave & 3) * XTW) + l31;
-            float *T3w = (float *)(smb + XSHARED + 4 * XTW + wave * (9 * XTROW));
+            // T2 (level-2 rows): under the turn protocol shared by wave w and w + 4 (their folds never overlap: G1's is over
+            // before e3, G0's runs between e3 and e4), else one per wave; T3 (9 level-3 rows) is private
+            float *Tw = (float *)(smb + XSHARED + (wave & (XT2N - 1)) * XTW) + l31;
+            float *T3w = (float *)(smb + XSHARED + XT2N * XTW + wave * (9 * XTROW));
             const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
-#else
-            float *Tw = (float *)(smb + XSHARED + wave * XTW) + l31;
-#endif
             // The K-ranges (tap, image) are walked in 18 steps.  A step = the pixel slabs of level 1 (P), the cell slabs
             // of levels 2 + 3 (C) and the fold (F).  Waves 0-3 run P(i) C(i) F(i); waves 4-7 -- each shares its SIMD with
             // one of waves 0-3 -- run C(i) F(i) P(i) (their weight stream is packed in that order), so that a fold, which
@@ -636,13 +670,13 @@ __global__ __launch_bounds__(NT, 2) void XN_KERNEL(RegressArgs args) {
                     XWADV(8) (void)a0; (void)a1; (void)sc;
 #else
                     XPRO(a0, a1, sc[0])
-                    XSLAB2(a0 + 64, a1 + 64, a0 + 128, a1 + 128, sc[0], sc[1])
-                    XSLAB(a0 + 192, a1 + 192, sc[0], sc[1], B0, B1, B2, B3, 2)
-                    XSLABEND(sc[1], B2, B3, B0, B1, 4)
-                    XWADV(4)
+                    XGROUP4(XSLAB(a0 + 64, a1 + 64, sc[0], sc[1], B0, B1, B6, B7, 6),
+                            XSLAB(a0 + 128, a1 + 128, sc[0], sc[1], B2, B3, B0, B1, 8),
+                            XSLAB(a0 + 192, a1 + 192, sc[0], sc[1], B4, B5, B2, B3, 10),
+                            XSLABEND(sc[1], B6, B7, B4, B5, 12))
 #endif
                     XPB_P1()
-                    XT(4)
+                    XTL(4)
                 }
                 if (it < 18) {      // ---- C(it), F(it): levels 2 (64 ch) + 3 (128 ch), cell rows, pre-split planes
                     const int tap = it >> 1, img = it & 1;
@@ -662,7 +696,9 @@ __global__ __launch_bounds__(NT, 2) void XN_KERNEL(RegressArgs args) {
                     const unsigned char *q2 = smb + a2, *q3 = smb + a3;
                     f32x16 t0, t1;
                     XPB_C0(grp)
-#if defined(XF_L3_16)
+#if defined(XF_SKIP_C)
+                    t0 = acc00; t1 = acc01; XWADV(24) (void)q2; (void)q3;
+#elif defined(XF_L3_16)
                     {
                         (void)q3;
                         // level 3 first: 4 K steps of 32 channels x 4 n-tiles of 16 columns, rows = the 9 cells
@@ -670,18 +706,14 @@ __global__ __launch_bounds__(NT, 2) void XN_KERNEL(RegressArgs args) {
                         const unsigned char *q3r = smb + img * XIMG + YOFF3 + ((l16 < 9) ? l16 : YNC3) * YST3 + kb * 16;
                         f32x4v u0, u1, u2, u3;
                         XLOADP(S0, q3r, YPL3)
-                        X16SLAB(X16HALFZ, u0, u1, S0, XLOADP(S1, q3r + 64, YPL3), B0, B1, B2, B3, 2)
-                        X16SLAB(X16HALFZ, u2, u3, S0, , B2, B3, B0, B1, 4)
-                        XWADV(4)
-                        X16SLAB(X16HALF, u0, u1, S1, XLOADP(S0, q3r + 128, YPL3), B0, B1, B2, B3, 2)
-                        X16SLAB(X16HALF, u2, u3, S1, , B2, B3, B0, B1, 4)
-                        XWADV(4)
-                        X16SLAB(X16HALF, u0, u1, S0, XLOADP(S1, q3r + 192, YPL3), B0, B1, B2, B3, 2)
-                        X16SLAB(X16HALF, u2, u3, S0, , B2, B3, B0, B1, 4)
-                        XWADV(4)
-                        X16SLAB(X16HALF, u0, u1, S1, XLOADP(S0, q2, YPL2), B0, B1, B2, B3, 2)
-                        X16SLAB(X16HALF, u2, u3, S1, , B2, B3, B0, B1, 4)
-                        XWADV(4)
+                        XGROUP4(X16SLAB(X16HALFZ, u0, u1, S0, XLOADP(S1, q3r + 64, YPL3), B0, B1, B6, B7, 6),
+                                X16SLAB(X16HALFZ, u2, u3, S0, , B2, B3, B0, B1, 8),
+                                X16SLAB(X16HALF, u0, u1, S1, XLOADP(S0, q3r + 128, YPL3), B4, B5, B2, B3, 10),
+                                X16SLAB(X16HALF, u2, u3, S1, , B6, B7, B4, B5, 12))
+                        XGROUP4(X16SLAB(X16HALF, u0, u1, S0, XLOADP(S1, q3r + 192, YPL3), B0, B1, B6, B7, 6),
+                                X16SLAB(X16HALF, u2, u3, S0, , B2, B3, B0, B1, 8),
+                                X16SLAB(X16HALF, u0, u1, S1, XLOADP(S0, q2, YPL2), B4, B5, B2, B3, 10),
+                                X16SLAB(X16HALF, u2, u3, S1, , B6, B7, B4, B5, 12))
                         // T3[row = 4 * kb + r][column 16 * nt + l16]
                         P2P_WAVE_SYNC();
 #pragma unroll
@@ -691,41 +723,21 @@ __global__ __launch_bounds__(NT, 2) void XN_KERNEL(RegressArgs args) {
                                 d[0] = u0[r]; d[16] = u1[r]; d[32] = u2[r]; d[48] = u3[r];
                             }
                         // level 2: 4 slabs of 16 channels, rows = level-2 cells
-                        XCSLAB(XHALFZ, S0, S1, q2 + 32, YPL2, B0, B1, B2, B3, 2)
-                        XCSLAB(XHALF, S1, S0, q2 + 64, YPL2, B2, B3, B0, B1, 4)
-                        XWADV(4)
-                        XCSLAB(XHALF, S0, S1, q2 + 96, YPL2, B0, B1, B2, B3, 2)
-                        XCSLAB(XHALF, S1, S0, q2 + 96, YPL2, B2, B3, B0, B1, 4)
-                        XWADV(4)
-                    }
-#elif defined(XF_SKIP_C)
-                    t0 = acc00; t1 = acc01; XWADV(24) (void)q2; (void)q3;
-#else
-                    // 12 slabs of 16 channels = 32 bytes of bf16 per plane
-                    XLOADP(S0, q2, YPL2)
-                    XCSLAB(XHALFZ, S0, S1, q2 + 32, YPL2, B0, B1, B2, B3, 2)
-                    XCSLAB(XHALF, S1, S0, q2 + 64, YPL2, B2, B3, B0, B1, 4)
-                    XWADV(4)
-                    XCSLAB(XHALF, S0, S1, q2 + 96, YPL2, B0, B1, B2, B3, 2)
-                    XCSLAB(XHALF, S1, S0, q3, YPL3, B2, B3, B0, B1, 4)
-                    XWADV(4)
-#pragma unroll 1
-                    for (int g = 0; g < 4; ++g) {
-                        const int gn = (g < 3) ? 2 * g + 2 : 7;
-                        XCSLAB(XHALF, S0, S1, q3 + (2 * g + 1) * 32, YPL3, B0, B1, B2, B3, 2)
-                        XCSLAB(XHALF, S1, S0, q3 + gn * 32, YPL3, B2, B3, B0, B1, 4)
-                        XWADV(4)
+                        XGROUP4(XCSLAB(XHALFZ, S0, S1, q2 + 32, YPL2, B0, B1, B6, B7, 6),
+                                XCSLAB(XHALF, S1, S0, q2 + 64, YPL2, B2, B3, B0, B1, 8),
+                                XCSLAB(XHALF, S0, S1, q2 + 96, YPL2, B4, B5, B2, B3, 10),
+                                XCSLAB(XHALF, S1, S0, q2 + 96, YPL2, B6, B7, B4, B5, 12))
                     }
 #endif
                     XPB_C1(grp)
-                    XT(5)
+                    XTL(5)
 #ifndef XF_SKIP_FOLD
                     // fold: acc[pixel][n] += scale[pixel] * T[cell row of the pixel][n]
                     P2P_WAVE_SYNC();            // the wave's previous fold has read T
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2);              // + 4 * half
-                        if (r < 12 || half == 0) {
+                        if ((r < 12 || half == 0) && row + 4 * half < XTROWS) {
                             Tw[(row + 4 * half) * 64] = t0[r];
                             Tw[(row + 4 * half) * 64 + 32] = t1[r];
                         }
@@ -758,20 +770,22 @@ __global__ __launch_bounds__(NT, 2) void XN_KERNEL(RegressArgs args) {
                     acc00 += t0; acc01 += t1;
 #endif
                     XPB_F(stagger, grp)
-                    XT(6)
+                    XTL(6)
                 }
             }
         }
         __syncthreads();   // all waves are done reading the conv1 operands
         XT(7)
 
-        // BN1; chunk 0 of H (channels of waves 0, 1) -> three planes, the other chunks wait as fp32
+        // BN1 -> H.  Two planes: every wave writes the planes of its 64 channels into its chunk (wave >> 1).  Three planes:
+        // chunk 0 (channels of waves 0, 1) as planes, the other chunks wait as fp32
         {
-            if (tidv < XNPL * (HST / 16)) {  // the all-zero padding row of every plane
-                const int pl = tidv / (HST / 16), q = tidv - pl * (HST / 16);
+            if (tidv < 4 * XNPL * (HST / 16)) {  // the all-zero padding row of every plane (of every chunk)
+                const int ch = tidv / (XNPL * (HST / 16)), pq = tidv - ch * (XNPL * (HST / 16));
+                const int pl = pq / (HST / 16), q = pq - pl * (HST / 16);
                 float zf = 0.f;
                 P2P_OPAQUE(zf);
-                *(f32x4 *)(smb + pl * HPL + 64 * HST + q * 16) = (f32x4){zf, zf, zf, zf};
+                if (HCHUNK != 0 || ch == 0) *(f32x4 *)(smb + ch * HCHUNK + pl * HPL + 64 * HST + q * 16) = (f32x4){zf, zf, zf, zf};
             }
             const int chunk = wave >> 1;
             const int hv = half, lv = l31;
@@ -800,8 +814,15 @@ __global__ __launch_bounds__(NT, 2) void XN_KERNEL(RegressArgs args) {
                 const int n = wave * 64 + u * 32 + lv;
                 const int cc = (wave & 1) * 64 + u * 32 + lv;                // channel inside the chunk
                 const float s = R_.XN_BN1S[n], b = R_.bn1b[n];
+#if XNPL == 2
+                // channels (cc, cc + 1) sit in adjacent lanes: the even lane stores the pair's first plane, the odd lane its
+                // second plane -- one 4-byte store per value instead of two 2-byte ones
+                const bool odd = lv & 1;
+                unsigned char *dplane = smb + chunk * HCHUNK + (odd ? HPL : 0) + 4 * hv * HST + (cc & ~1) * 2;
+#else
                 unsigned char *dplane = smb + 4 * hv * HST + cc * 2;
                 unsigned char *dpark = smb + XPARK + (chunk - 1) * XPARKCH + 4 * hv * XPARKST + cc * 4;
+#endif
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const f32x16 &a = (t == 0) ? (u == 0 ? acc00 : acc01) : (u == 0 ? acc10 : acc11);
@@ -813,11 +834,18 @@ __global__ __launch_bounds__(NT, 2) void XN_KERNEL(RegressArgs args) {
 #else
                         const float v = fmaf(a[r], s, b);
 #endif
+#if XNPL == 2
+                        const unsigned short h0 = f2e(v), h1 = f2e(v - e2f(h0));
+                        const unsigned mine = odd ? h1 : h0, give = odd ? h0 : h1;   // keep the half of my plane, hand the other to the partner
+                        const unsigned got = P2P_SWAP_ADJACENT(give);
+                        *(unsigned *)(dplane + p * HST) = odd ? (got | mine << 16) : (mine | got << 16);
+#else
                         if (chunk == 0) {
                             store_planes(dplane + p * HST, HPL, v);
                         } else {
                             *(float *)(dpark + p * XPARKST) = v;
                         }
+#endif
                     }
                 }
             }
@@ -832,10 +860,12 @@ __global__ __launch_bounds__(NT, 2) void XN_KERNEL(RegressArgs args) {
             f32x4 A00[XNPL], A01[XNPL], A10[XNPL], A11[XNPL];   // [buffer][m-tile][plane]
             // weights: ring of 8 units = 4 slabs, loaded THREE slabs ahead (a third of the stream misses L2 and comes
             // from the Infinity Cache: ~1 us, more than the ~0.8 us one slab of both waves of the SIMD lasts)
-            f32x4 B4[XNPL], B5[XNPL], B6[XNPL], B7[XNPL];
             XLOADB(B0, 0) XLOADB(B1, 1) XLOADB(B2, 2) XLOADB(B3, 3) XLOADB(B4, 4) XLOADB(B5, 5)
 #pragma unroll 1
             for (int chunk = 0; chunk < 4; ++chunk) {
+#if XNPL == 2
+                if (chunk == 0) __syncthreads();       // H is complete; the four chunks need no further hand-over
+#else
                 if (chunk > 0) {
                     __syncthreads();       // everybody has read the previous chunk's planes
                     // fp32 -> three planes, whole work-group: 64 px x 32 groups of 4 channels
@@ -852,9 +882,7 @@ __global__ __launch_bounds__(NT, 2) void XN_KERNEL(RegressArgs args) {
                             const unsigned mm = pk_e(r0, r1);
                             pl[0][h] = hh;
                             pl[1][h] = mm;
-#if XNPL == 3
                             pl[2][h] = pk_e(r0 - pk_lo(mm), r1 - pk_hi(mm));
-#endif
                         }
                         unsigned char *dst = smb + p * HST + q * 8;
 #pragma unroll
@@ -863,6 +891,7 @@ __global__ __launch_bounds__(NT, 2) void XN_KERNEL(RegressArgs args) {
                     }
                 }
                 __syncthreads();
+#endif
                 XT(9)
                 // A addresses of a tap: pixel rows of the two m-tiles (row 64 = zeros outside the 8x8 map)
                 auto rows = [&](int tap, const unsigned char *&p0, const unsigned char *&p1) {
@@ -871,13 +900,13 @@ __global__ __launch_bounds__(NT, 2) void XN_KERNEL(RegressArgs args) {
                     const bool okx = (ox >= 0) && (ox < 8);
                     const bool ok0 = okx && (oy >= 0);
                     const bool ok1 = okx && (oy + 4 < 8);
-                    p0 = smb + (ok0 ? oy * 8 + ox : 64) * HST + half * 16;
-                    p1 = smb + (ok1 ? (oy + 4) * 8 + ox : 64) * HST + half * 16;
+                    p0 = smb + chunk * HCHUNK + (ok0 ? oy * 8 + ox : 64) * HST + half * 16;
+                    p1 = smb + chunk * HCHUNK + (ok1 ? (oy + 4) * 8 + ox : 64) * HST + half * 16;
                 };
                 const unsigned char *p0, *p1;
                 rows(0, p0, p1);
                 XLOADP(A00, p0, HPL) XLOADP(A01, p1, HPL)
-#ifndef XF_NO_PINGPONG
+#if XF_TURNS2
                 if (wave >= 4) __builtin_amdgcn_s_barrier();        // waves 4-7 take the second turn
 #endif
 #ifdef XF_SKIP_CONV2
@@ -907,7 +936,7 @@ __global__ __launch_bounds__(NT, 2) void XN_KERNEL(RegressArgs args) {
                     XWADV(8)
                     p0 = n0; p1 = n1;
                 }
-#ifndef XF_NO_PINGPONG
+#if XF_TURNS2
                 if (wave < 4) __builtin_amdgcn_s_barrier();         // every wave has executed the same number of barriers
 #endif
                 XT(10)
@@ -933,26 +962,30 @@ __global__ __launch_bounds__(NT, 2) void XN_KERNEL(RegressArgs args) {
                     m = fmaxf(m, fmaf(ab2[r], s, b));
                 }
                 m = fmaxf(m, __shfl_xor(m, 32));
-                if (half == 0) V[n] = m;
+                if (half == 0) XWS_V(lvl)[(size_t)prop * 512 + n] = m;       // pooled features: the FC batch of the level reads them back
             }
         }
-        __syncthreads();
+        __syncthreads();       // every wave is done with the proposal's LDS (the next gather overwrites it)
         XT(11)
-
-#ifdef XF_SKIP_FC                       // timing experiment (wrong results)
-        __syncthreads();
-#else
-        fc_tail_parse(R_, I, args, lvl, prop, tidv, V, F1, F2, misc);
-#endif
-        XT(12)
 #ifdef P2P_X3_TIMING
-        // raw[0] doubles as the stamp buffer in timing builds: workgroups < 64 record [prop][wave][16] phase lengths
-        if (args.raw[0] && prop < 64 && (tidv & 63) == 0 && lvl == 0) {
-            float *dbg = args.raw[0] + 5 * args.n + (prop * 8 + wave) * 16;
+        // raw[0] doubles as the stamp buffer in timing builds: work-groups < 64 record [group][wave][16] phase lengths of the
+        // middle proposal of their share
+        if (args.raw[0] && blockIdx.x < 64 && prop / nwg == (args.n / nwg) / 2 && (tidv & 63) == 0 && lvl == 0) {
+            float *dbg = args.raw[0] + 5 * args.n + (blockIdx.x * 8 + wave) * 16;
 #pragma unroll
-            for (int i = 0; i < 13; ++i) dbg[i] = (float)xt_[i];
+            for (int i = 0; i < 13; ++i) dbg[i] = (float)XTL_()[i];
         }
 #endif
+      }
+        // ------------------------------------------------------------ FC tail of all this work-group's proposals
+        __builtin_amdgcn_s_setprio(0);
+        __threadfence();       // the V rows written above are visible to the (cache-bypassing) loads of the batch
+        __syncthreads();
+#ifndef XF_SKIP_FC                      // timing experiment (wrong results)
+        fc_batch_parse(R_, args, lvl, XWS_V(lvl), XWS_NEXTP(), smb, tid);
+#endif
+        __threadfence();       // ... and the regressed matches to the next level's proposal loads
+        __syncthreads();
     }
 }
 
@@ -1015,11 +1048,7 @@ void XN_PACK(const float *conv1_w, const float *conv2_w, float *wx1, float *wx2,
             // stream position -> canonical slab (split_conv1_index): waves 4-7 walk every (tap, image) step as
             // [12 cell slabs of levels 2 + 3][4 pixel slabs of level 1], waves 0-3 the other way round
             int slab = pos;
-#ifdef XF_PPAR
-            if (false) {
-#else
             if (w >= 4 && pos >= 4) {
-#endif
                 const int step = (pos - 4) / 16, j = (pos - 4) % 16;
                 slab = 4 + step * 16 + ((j < 12) ? 4 + j : j - 12);
             }
@@ -1079,12 +1108,19 @@ int XN_LAUNCH(const RegressArgs &a, int n, hipStream_t stream) {
     int dev = 0;
     P2P_HIP_CHECK(hipGetDevice(&dev));
     static bool attr_set[64] = {false};
-    if (dev < 64 && !attr_set[dev]) {
+    static int cus[64] = {0};
+    if (dev >= 64 || !attr_set[dev]) {
         P2P_HIP_CHECK(hipFuncSetAttribute((const void *)XN_KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)XSM_BYTES));
-        attr_set[dev] = true;
+        int ncu = 0;
+        P2P_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        if (dev < 64) { cus[dev] = ncu; attr_set[dev] = true; }
+        else cus[0] = ncu;
     }
-    hipLaunchKernelGGL(XN_KERNEL, dim3(n), dim3(NT), XSM_BYTES, stream, a);
+    // persistent work-groups: one fits a compute unit (LDS), each walks its share of the proposals
+    const int ncu = cus[dev < 64 ? dev : 0];
+    P2P_REQUIRE(a.ws, P2P_EINVAL, "%s: the scratch buffer is missing", XN_NAME);
+    hipLaunchKernelGGL(XN_KERNEL, dim3(std::min(n, std::max(ncu, 1))), dim3(NT), XSM_BYTES, stream, a);
     return check_launch(XN_NAME);
 }
 

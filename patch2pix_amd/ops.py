@@ -34,6 +34,10 @@ class NcnWeights:
             _lib.check(_lib.p2p_ncn_create(*[t.data_ptr() for t in keep], ctypes.byref(self.handle)), "p2p_ncn_create")
         self.device = torch.device(device)
 
+    def set_tile(self, ta=0, tb=0, tc=0):
+        """Force the work-group tile of the consensus kernel (tests, sweeps); (0, 0, 0) = automatic.  Results do not depend on it."""
+        _lib.check(_lib.p2p_ncn_set_tile(self.handle, int(ta), int(tb), int(tc)), "p2p_ncn_set_tile")
+
     def __del__(self):
         if getattr(self, "handle", None) and _lib is not None:      # _lib is None during interpreter shutdown
             _lib.p2p_ncn_destroy(self.handle)
@@ -165,9 +169,9 @@ class RegressorWeights:
         self.device = torch.device(device)
 
     def set_mode(self, mode):
-        """'fp16x2' (default: fp32-equivalent, two fp16 planes under exact power-of-two scales, 3 MFMA products), 'bf16x3'
-        (fp32-equivalent, three bf16 planes, 6 products), 'f32' (exact fp32 MFMA) or
-        'bf16x2' (reduced precision, 16 significant bits; opt-in)."""
+        """'fp16x2' (default: fp32-equivalent, two fp16 planes under exact power-of-two scales, 3 MFMA products), 'f32'
+        (exact fp32 MFMA) or 'bf16x2' (reduced precision, 16 significant bits; opt-in).  The first selection of a
+        non-default mode packs and uploads that mode's weight stream (host work, ~1 s)."""
         _lib.check(_lib.p2p_regressor_set_mode(self.handle, _lib.REGRESS_MODES[mode]), "p2p_regressor_set_mode")
 
     @property
@@ -414,12 +418,20 @@ def regress_batch_dev(reg1, reg2, pyrs1, pyrs2, proposals, counts, want_raw=Fals
     g = lambda k: out[k].data_ptr() if k in out else None
     if nb and stride:
         with torch.cuda.device(dev):
+            ws = _regress_scratch(dev, nb * stride)
             _lib.check(_lib.p2p_regress_batch_dev(reg1.handle, reg2.handle if two else None, nb, pyr_a, pyr_b,
                                                   counts.data_ptr(), stride, proposals.data_ptr(),
                                                   int(proposals.is_floating_point()), g("matches1"), g("probs1"), g("raw1"),
-                                                  g("matches2"), g("probs2"), g("raw2"), _stream()), "p2p_regress_batch_dev")
+                                                  g("matches2"), g("probs2"), g("raw2"), ws.data_ptr(), ws.numel(), _stream()),
+                       "p2p_regress_batch_dev")
     del keep
     return out
+
+
+def _regress_scratch(dev, n):
+    """Scratch of one regress launch (the pooled convolution features wait there for the batched FC tail): a fresh
+    stream-ordered allocation per call, so that launches on different streams never share it."""
+    return torch.empty(_lib.p2p_regress_workspace_bytes(int(n)), dtype=torch.uint8, device=dev)
 
 
 def _pyramid(levels):
@@ -489,13 +501,14 @@ def regress_batch(reg1, reg2, pyrs1, pyrs2, proposals, want_mid=True, want_raw=F
     r2 = buf("raw2", 5, two and want_raw)
     if n:
         with torch.cuda.device(dev):
+            ws = _regress_scratch(dev, n)
             ev = None
             if regress_events is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
             _lib.check(_lib.p2p_regress_batch(reg1.handle, reg2.handle if two else None, nitems, pyr_a, pyr_b, cnt,
-                                              allp.data_ptr(), is_float, m1, q1, r1, m2, q2, r2, _stream()),
-                       "p2p_regress_batch")
+                                              allp.data_ptr(), is_float, m1, q1, r1, m2, q2, r2, ws.data_ptr(), ws.numel(),
+                                              _stream()), "p2p_regress_batch")
             if ev is not None:
                 ev[1].record()
                 regress_events.append((ev[0], ev[1], n, 2 if two else 1))

@@ -97,6 +97,13 @@ def regressor_create(emu, sd, mode):
     return h
 
 
+def regress_scratch(emu, n):
+    """(keep-alive tensor, 128-byte aligned address, bytes) of the scratch p2p_regress* needs for n proposal slots."""
+    need = emu.p2p_regress_workspace_bytes(int(n))
+    ws = torch.empty(need + 128, dtype=torch.uint8)
+    return ws, ctypes.c_void_p((ws.data_ptr() + 127) & ~127), need
+
+
 def regress(emu, reg1, reg2, pyr1, pyr2, proposals):
     """One pair through p2p_regress_batch: pyr*: the 4 maps of feat_idx [0,1,2,3] (CPU fp32), proposals [n,4]
     int64 or float32.  Returns dict matches1/probs1/raw1 (+ *2 with reg2)."""
@@ -116,11 +123,12 @@ def regress(emu, reg1, reg2, pyr1, pyr2, proposals):
     two = reg2 is not None
     arr_a, arr_b = (real.Pyramid * 1)(pa), (real.Pyramid * 1)(pb)
     cnt = (ctypes.c_int * 1)(n)
+    ws, wsp, wsn = regress_scratch(emu, n)
     check(emu, emu.p2p_regress_batch(reg1, reg2 if two else None, 1, arr_a, arr_b, cnt, proposals.data_ptr(),
                                      int(proposals.is_floating_point()), out["matches1"].data_ptr(),
                                      out["probs1"].data_ptr(), out["raw1"].data_ptr(),
                                      out["matches2"].data_ptr() if two else None, out["probs2"].data_ptr() if two else None,
-                                     out["raw2"].data_ptr() if two else None, None), "p2p_regress_batch")
+                                     out["raw2"].data_ptr() if two else None, wsp, wsn, None), "p2p_regress_batch")
     del ka, kb
     return out
 

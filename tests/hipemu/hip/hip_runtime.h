@@ -64,6 +64,14 @@ enum { hipSuccess = 0, hipErrorUnknown = 999 };
 typedef struct hipemu_stream *hipStream_t;
 enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+// three "compute units" (HIPEMU_CUS overrides, read at the first query): launches of persistent work-groups walk several
+// items each
+static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) {
+    const char *e = getenv("HIPEMU_CUS");
+    *v = e ? atoi(e) : 3;
+    return hipSuccess;
+}
 static inline const char *hipGetErrorString(hipError_t) { return "hipemu"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
@@ -104,11 +112,13 @@ static inline float unsafeAtomicAdd(float *p, float v) {
     } while (!__atomic_compare_exchange_n((unsigned *)p, &old, want, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
     return cur;
 }
+#define __threadfence() __sync_synchronize()
 #define __builtin_amdgcn_readfirstlane(x) (x)      /* only applied to wave-uniform values in these kernels */
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(mask, n, id) ((void)0)
 #define __builtin_amdgcn_s_memtime() (0ull)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_amdgcn_s_barrier() hipemu::sync_block()
 
 template <class T> static inline T __shfl_xor(T v, int mask) {
@@ -142,6 +152,25 @@ static inline hipemu_f32x16 hipemu_mfma_32x32x2_f32(float a, float b, hipemu_f32
     return c;
 }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu_mfma_32x32x2_f32((a), (b), (c))
+
+// v_mfma_f32_16x16x4_f32: D = A(16x4) B(4x16) + C.  Lane l holds A[l&15][l>>4], B[l>>4][l&15]; register r of C/D is row
+// 4*(l>>4) + r, column l&15.
+typedef float hipemu_f32x4_ __attribute__((ext_vector_type(4)));
+static inline hipemu_f32x4_ hipemu_mfma_16x16x4_f32(float a, float b, hipemu_f32x4_ c) {
+    struct { float a, b; } mine = {a, b};
+    const unsigned char *all = hipemu::wave_gather(&mine, sizeof(mine));
+    const int lane = hipemu::ctx().thread.x & 63, col = lane & 15, blk = lane >> 4;
+    auto A = [&](int row, int k) { float v; memcpy(&v, all + (row + 16 * k) * 8, 4); return v; };
+    auto B = [&](int k, int cc) { float v; memcpy(&v, all + (cc + 16 * k) * 8 + 4, 4); return v; };
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * blk + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(A(row, k), B(k, col), acc);
+        c[r] = acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu_mfma_16x16x4_f32((a), (b), (c))
 
 // v_mfma_f32_32x32x16_bf16: A 32x16, B 16x32 in bf16, fp32 accumulate.  Lane l holds A[l&31][8*(l>>5) + i],
 // B[8*(l>>5) + i][l&31], i = 0..7; C/D as above.

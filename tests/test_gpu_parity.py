@@ -34,12 +34,14 @@ def ops():
     return ops
 
 
-MODES = ["bf16x3", "fp16x2", "f32", "bf16x2"]   # fp32-equivalent (three bf16 planes / two fp16 planes), exact fp32 MFMA, reduced precision (opt-in)
+MODES = ["fp16x2", "f32", "bf16x2"]   # fp32-equivalent on two fp16 planes (the default), exact fp32 MFMA, reduced precision (opt-in)
+DEFAULT_MODE = "fp16x2"                         # include/p2p_hip.h: P2P_REGRESS_DEFAULT
 
 
 @pytest.fixture(scope="module")
 def cweights(dev, ops):
-    """Coarse-stage weights (the coarse stage has one arithmetic: fp32)."""
+    """Coarse-stage weights.  The coarse stage has ONE arithmetic whatever the batch: fp32-equivalent fp16x2 (correlation
+    GEMM and the fused consensus kernel on the fp16 matrix cores, everything else fp32)."""
     sd = gu.state_dict(0)
     ncn = ops.NcnWeights(sd["ncn.conv.0.weight"], sd["ncn.conv.0.bias"], sd["ncn.conv.2.weight"],
                          sd["ncn.conv.2.bias"], dev)
@@ -134,36 +136,21 @@ def test_fused_consensus_vs_oracle(dims, dev, ops, cweights):
     assert torch.equal(ops.neigh_consensus_batch(x.to(dev), ncn).cpu(), y), "the fused consensus kernel is not deterministic"
 
 
-@pytest.mark.parametrize("tile", ["2,3,2", "4,6,6", "0,2,5", "3,4,3", "30,6,6"])
-def test_fused_consensus_tilings(tile, dev, ops, cweights, monkeypatch):
+def test_fused_consensus_tilings(dev, ops, cweights):
     """The fused consensus kernel marches along the first axis in chunks of `ta` slices over tiles of tb x tc cells; the
-    tile is normally picked from the volume and batch size.  Force several (ta,tb,tc) shapes (0 = pick ta), including
-    chunks that do not divide the axes."""
-    sd, ncn = cweights[0], cweights[1]
-    monkeypatch.setenv("P2P_NCF_TILE", tile)
+    tile is normally picked from the volume and batch size.  Forced (ta,tb,tc) shapes (0 = pick ta), including chunks that
+    do not divide the axes, against the oracle -- and BIT-IDENTICAL to each other: every output cell sums the contributions
+    of its 3 x 3 hidden strips in one fixed order whatever the tile."""
+    sd = cweights[0]
+    ncn = ops.NcnWeights(sd["ncn.conv.0.weight"], sd["ncn.conv.0.bias"], sd["ncn.conv.2.weight"], sd["ncn.conv.2.bias"], dev)
     x = torch.rand(1, 7, 11, 7, 11, generator=torch.Generator().manual_seed(5))
     o_ncn, _, _ = orc.split_params(sd)
     ref = orc.neigh_consensus(x[0], o_ncn)
-    assert (ops.neigh_consensus_batch(x.to(dev), ncn).cpu()[0] - ref).abs().max() <= 3e-6 * ref.abs().max()
-
-
-@pytest.mark.parametrize("tile", ["2,4,2,2,128", "3,5,3,3,256", "4,6,2,4,128", "2,4,3,30,256", "5,10,2,1,256"])
-def test_consensus_layer2_tilings(tile, dev, ops, cweights, monkeypatch):
-    """The second consensus layer marches along the first axis in chunks of `ta` slices; the tile is normally picked
-    from the volume and batch size.  Force several (tb,tc,tdr,ta,threads) shapes, including chunks that do not
-    divide the axis and d-tiles narrower than the volume, on a volume small enough for the oracle."""
-    sd, ncn, _, _ = cweights
-    monkeypatch.setenv("P2P_NC2_TILE", tile)
-    H, W = 112, 176                                     # pooled volume 7 x 11 x 7 x 11
-    p1, p2 = synthetic.make_correlated_pyramids(321, H, W)
-    o_ncn, _, _ = orc.split_params(sd)
-    rc, rd = orc.coarse_forward(p1[4], p2[4], 2, o_ncn)
-    corr, _ = ops.coarse_forward(p1[4].to(dev), p2[4].to(dev), 2, ncn)
-    np.testing.assert_allclose(corr.cpu().numpy(), rc.numpy(), rtol=2e-4, atol=1e-7)
-    # a wider volume (k = 1: 14 x 22 x 14 x 22, last axis not a multiple of 4 -> row-wise staging)
-    rc1, _ = orc.coarse_forward(p1[4], p2[4], 1, o_ncn)
-    corr1, _ = ops.coarse_forward(p1[4].to(dev), p2[4].to(dev), 1, ncn)
-    np.testing.assert_allclose(corr1.cpu().numpy(), rc1.numpy(), rtol=2e-4, atol=1e-7)
+    base = ops.neigh_consensus_batch(x.to(dev), ncn).cpu()
+    assert (base[0] - ref).abs().max() <= 3e-6 * ref.abs().max()
+    for tile in ((2, 3, 2), (4, 6, 6), (0, 2, 5), (3, 4, 3), (30, 6, 6)):
+        ncn.set_tile(*tile)
+        assert torch.equal(ops.neigh_consensus_batch(x.to(dev), ncn).cpu(), base), tile
 
 
 @pytest.mark.parametrize("ksize", [1, 2])
@@ -187,6 +174,42 @@ def test_coarse_batch_equals_per_pair(ksize, dev, ops, cweights, monkeypatch):
                 assert torch.equal(delta[i], singles[i][1]), (limit, i)
             m1, s1 = ops.coarse_matches(singles[i][0], singles[i][1], ksize, 8, True)
             assert torch.equal(m[i], m1) and torch.equal(sc[i], s1), (limit, i)
+
+
+def test_pair_results_do_not_depend_on_the_batch(dev, ops, cweights):
+    """The reference treats batch items independently (networks/patch2pix.py:120-136, ncn/conv4d.py:47-71).  Here too: a
+    480x640 pair's corr4d, relocalisation codes, coarse rows and -- through the default regressors -- its mid / fine matches
+    are BIT-IDENTICAL whether the pair is launched alone, in a batch of 8 or in a batch of 16, and for every forced tile of
+    the consensus kernel (estimate_matches and estimate_matches_stream therefore agree bit for bit)."""
+    from patch2pix_amd.networks.utils import filter_coarse
+    sd = cweights[0]
+    ncn = ops.NcnWeights(sd["ncn.conv.0.weight"], sd["ncn.conv.0.bias"], sd["ncn.conv.2.weight"], sd["ncn.conv.2.bias"], dev)
+    sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+    mid_w, fine_w = ops.RegressorWeights(sub("regress_mid."), dev), ops.RegressorWeights(sub("regress_fine."), dev)
+    H, W, B = 480, 640, 16
+    pairs = [synthetic.make_correlated_pyramids(3000 + i, H, W) for i in range(B)]
+    fa = torch.stack([p[0][4] for p in pairs]).to(dev)
+    fb = torch.stack([p[1][4] for p in pairs]).to(dev)
+
+    def run(nb, tile=(0, 0, 0)):
+        ncn.set_tile(*tile)
+        corr, delta = ops.coarse_forward_batch(fa[:nb], fb[:nb], 2, ncn)
+        m, sc = ops.coarse_matches_batch(corr, delta, 2, 8, True)
+        return corr[0].clone(), delta[0].clone(), m[0].clone(), sc[0].clone()
+
+    base = run(1)
+    for nb, tile in ((8, (0, 0, 0)), (16, (0, 0, 0)), (1, (4, 5, 8)), (1, (30, 5, 8)), (16, (7, 3, 6)), (2, (15, 6, 4))):
+        got = run(nb, tile)
+        for k, (a, b) in enumerate(zip(got, base)):
+            assert torch.equal(a, b), f"batch {nb}, tile {tile}: output {k} of pair 0 differs from the single-pair launch"
+    ncn.set_tile(0, 0, 0)
+    cm, _ = filter_coarse(base[2][None], base[3][None], 0.0, True)
+    props = [cm[0]] + [torch.randint(8, 400, (300, 4), generator=torch.Generator().manual_seed(i)).to(dev) for i in range(1, 4)]
+    pyr = lambda i, s: _gpu(pairs[i][s][:4], dev)
+    alone = ops.regress(mid_w, fine_w, pyr(0, 0), pyr(0, 1), props[0])
+    batch = ops.regress_batch(mid_w, fine_w, [pyr(i, 0) for i in range(4)], [pyr(i, 1) for i in range(4)], props)
+    for k in ("matches1", "probs1", "matches2", "probs2"):
+        assert torch.equal(alone[k], batch[0][k]), k
 
 
 # ------------------------------------------------------------------------------------------ fine
@@ -387,7 +410,7 @@ def test_coarse_full_size_vs_oracle(dev, ops, cweights):
     print(f"\n{len(flips)} of {got.size} relocalisation argmaxes differ from the fp32 oracle:")
     for cell, g, r, gap, bound in flips:
         print(f"  cell {cell}: kernel {g}, oracle {r}, fp64 gap of the two candidates {gap:.3e} (fp32 error bound {bound:.1e})")
-        assert gap <= bound, f"cell {cell}: argmax differs but the candidates are {gap:.3e} apart in fp64 (bound {bound:.1e}: not a near-tie)"
+        assert gap <= 0.25 * bound, f"cell {cell}: argmax differs but the candidates are {gap:.3e} apart in fp64 (bound {bound:.1e}: not a near-tie)"
     assert len(flips) <= 8
     rm, rs = orc.cal_coarse_matches(rc, rd, 2, 8)
     m, s = ops.coarse_matches(corr, delta, 2, 8, True)
@@ -449,7 +472,7 @@ def test_benched_batch_path_vs_oracle(mode, dev):
     worst = dict(mid=0.0, fine=0.0, score=0.0)
     near_ties = 0
     with torch.no_grad():
-        for b in range(B if mode == MODES[0] else 3):   # all 16 pairs in the default mode, 3 in the others (CPU time)
+        for b in range(B if mode == DEFAULT_MODE else 3):   # all 16 pairs in the default mode, 3 in the others (CPU time)
             rc, rd = orc.coarse_forward(pairs[b][0][4], pairs[b][1][4], 2, o_ncn)
             rm, rs = orc.cal_coarse_matches(rc, rd, 2, 8)
             got_rows = ticket["matches"][b].cpu()

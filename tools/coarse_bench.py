@@ -6,6 +6,8 @@ from patch2pix_amd.utils import synthetic
 dev = torch.device("cuda:0")
 sd = synthetic.make_state_dict(0, backbone=False)
 ncn = ops.NcnWeights(sd["ncn.conv.0.weight"], sd["ncn.conv.0.bias"], sd["ncn.conv.2.weight"], sd["ncn.conv.2.bias"], dev)
+if os.environ.get("TILE"):      # force the consensus kernel's work-group tile "ta,tb,tc"
+    ncn.set_tile(*[int(v) for v in os.environ["TILE"].split(",")])
 H, W = int(os.environ.get("H", "480")), int(os.environ.get("W", "640"))
 p1, p2 = synthetic.make_correlated_pyramids(3, H, W)
 B = int(os.environ.get("BATCH", "1"))
@@ -17,4 +19,4 @@ a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True
 a.record()
 for _ in range(reps): ops.coarse_forward_batch(fa, fb, 2, ncn)
 b.record(); torch.cuda.synchronize()
-print(f"coarse_forward {H}x{W} batch {B}: {a.elapsed_time(b) / reps / B * 1e3:.1f} us per pair  (lib {os.environ.get('P2P_LIB_PATH', 'default')})", flush=True)
+print(f"coarse_forward {H}x{W} batch {B}: {a.elapsed_time(b) / reps / B * 1e3:.1f} us per pair  (lib {os.environ.get('P2P_LIB_PATH', 'default')}, tile {os.environ.get('TILE', 'auto')})", flush=True)

@@ -1,4 +1,4 @@
-"""Phase cycle counts of the bf16x3 kernel (needs the -DP2P_X3_TIMING build, P2P_LIB_PATH=tools/exp/lib_timing.so)."""
+"""Phase cycle counts of the fp16x2 regress kernel (needs the -DP2P_X3_TIMING build, P2P_LIB_PATH=tools/exp/lib_timing.so)."""
 import sys, os; sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import ctypes, torch
 from patch2pix_amd import ops, _lib
@@ -21,18 +21,19 @@ m1 = torch.empty((n, 4), device=dev); q1 = torch.empty((n,), device=dev); m2 = t
 raw = torch.zeros((5 * n + 64 * 8 * 16,), device=dev)
 MODE = os.environ.get('MODE', 'fp16x2')
 mid.set_mode(MODE); fine.set_mode(MODE)
+ws = torch.empty(_lib.p2p_regress_workspace_bytes(n), dtype=torch.uint8, device=dev)
 for _ in range(3):
     _lib.check(_lib.p2p_regress(mid.handle, fine.handle, ctypes.byref(pa), ctypes.byref(pb), props.data_ptr(), 0, n,
                                 m1.data_ptr(), q1.data_ptr(), raw.data_ptr(), m2.data_ptr(), q2.data_ptr(), None,
-                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "regress")
+                                ws.data_ptr(), ws.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "regress")
 torch.cuda.synchronize()
 d = raw[5 * n:].view(64, 8, 16).cpu()
 names = ["gather", "scale+tab", "im2col", "level0+sync", "P (level 1)", "C (levels 2+3)", "fold", "conv1 end sync", "BN1+H write",
-         "chunk convert+sync", "conv2 MFMA", "epilogue", "fc+parse"]
+         "conv2 entry sync", "conv2 MFMA", "epilogue+sync", "-"]
 for grp, sl in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
     med = [d[:, sl, i].median().item() for i in range(13)]
-    print(f"ticks per wave, median over 64 workgroups, {grp} (level 0):")
+    print(f"ticks per wave, median over 64 workgroups, {grp} (level 0, the middle proposal of the work-group's share):")
     for nme, v in zip(names, med):
         print(f"  {nme:20s} {v:9.0f}  ({100 * v / sum(med):4.1f} %)")
     print(f"  total                {sum(med):9.0f}")
-print("MFMA issue slots x 32 cycles x 2 waves per SIMD (bf16x3; fp16x2 = half): level0 6144, P 110592, C 165888, conv2 442368")
+print("MFMA issue slots x 32 cycles x 2 waves per SIMD: level0 3072, P 55296, C 82944, conv2 221184")
