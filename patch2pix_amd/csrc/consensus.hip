@@ -4,12 +4,15 @@
 // Work-group = one branch x one output tile [TA a][TB b][TC c][TD d] of the volume Y[a][b][c][d].  It walks the hidden
 // "strips" (a', b') that feed the tile, a' outer.  Per strip:
 //   S1  the 9 planes (da, db) of the input X (first MutualMatching applied) around the strip are staged in LDS as two fp16
-//       planes of X * 2^12 (|X| <= 1), rows c0-2 ... c0+TC+1, columns dt0-2 ... dt0+TD+1;
+//       planes of X * 2^12 (|X| <= 1), rows c0-2 ... c0+TC+1, columns dt0-2 ... dt0+TD+1 -- in a RING over b, so that a step
+//       along b restages only the three planes (da, b' + 1); their loads are prefetched a phase ahead and stored behind
+//       layer 2 of the strip before (one barrier per layer, none for the staging);
 //   S2  layer 1 on v_mfma_f32_32x32x16_f16: the hidden positions of the strip are FLAT (q = row * P + column, pitch P), an
-//       m-tile = 32 even positions, N = 16 channels x the position's two parities, K = 27 taps (da, db, dc) x a 4-wide
-//       window along d (the 3 taps dd of both parities): the A fragment of a lane is two aligned 8-byte reads of X, the
-//       weights (7 K-slabs, zero where a tap does not apply) live in registers.  bias + ReLU, zero outside the volume,
-//       hidden values as two fp16 planes [plane][8-channel half][position][8 channels] in LDS;
+//       n-tile = 32 even positions, M = 16 channels x the position's two parities, K = 27 taps (da, db, dc) x a 4-wide
+//       window along d (the 3 taps dd of both parities): the B fragment of a lane is two aligned 8-byte reads of X, the
+//       weights (A: 7 K-slabs, zero where a tap does not apply) live in registers; with the channels as ROWS a lane holds four
+//       consecutive channels of one position per register group.  bias + ReLU, zero outside the volume, hidden values as two
+//       fp16 planes [plane][8-channel half][position][8 channels] in LDS (one 8-byte store per group and plane);
 //   S3  layer 2 on v_mfma_f32_16x16x32_f16 in "gather" form over the B taps: an m-tile = 16 flat OUTPUT positions, K = 9 taps
 //       (dc, dd) x 16 channels (every A fragment is one aligned 16-byte read of the hidden planes), N = the 9 taps (da, db):
 //       column n is this strip's contribution to the output plane (a' - da + 1, b' - db + 1), added to the tile's
@@ -67,6 +70,34 @@ __device__ __forceinline__ float nh2f(unsigned short b) { return (float)__builti
 #define NCF_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(nh8, (a)), __builtin_bit_cast(nh8, (b)), (c), 0, 0, 0)
 #define NCF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(nh8, (a)), __builtin_bit_cast(nh8, (b)), (c), 0, 0, 0)
 
+// two fp32 -> one dword of two fp16 (round to nearest even): v_cvt_pk_f16_f32 (the bit_cast of a _Float16 pair)
+typedef _Float16 nh2 __attribute__((ext_vector_type(2)));
+typedef float nf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned npk(float x, float y) {
+    const nf2 v = {x, y};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, nh2));
+}
+__device__ __forceinline__ float npk_lo(unsigned h) { return (float)__builtin_bit_cast(nh2, h)[0]; }
+__device__ __forceinline__ float npk_hi(unsigned h) { return (float)__builtin_bit_cast(nh2, h)[1]; }
+
+// Staging of the input planes (S1).  One wave instruction moves two rows (lane >> 5) x 32 column PAIRS (lane & 31) of one
+// plane: an item = (plane, pair of rows), six row pairs per plane (XROWS <= 12).  The planes of a strip live in a RING over
+// b: slot (da, b mod 3), so a step along b restages only the three planes (da, b' + 1) -- NCF_KRING items per wave,
+// prefetched into registers a phase ahead -- and only the first strip of an a' row all nine (three such triples).
+#ifdef NCF_TIMING                       // phase lengths in s_memtime ticks, summed over the strips of one work-group (tools/ncf_timing.py)
+#define NT_DECL unsigned nt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned nt_last_ = (unsigned)__builtin_amdgcn_s_memtime();
+#define NT(i) { const unsigned n_ = (unsigned)__builtin_amdgcn_s_memtime(); nt_[i] += n_ - nt_last_; nt_last_ = n_; }
+#else
+#define NT_DECL
+#define NT(i)
+#endif
+constexpr int NCF_KRING = 5;     // items per wave and triple of planes: ceil(3 planes x 6 row pairs / 4 waves)
+
+// FIXED: the tile (tb, tc, td, P) = (5, 8, 40, 44) of every 480x640 / 960x1280 pair (pooled rows of 40 or 80 cells) as
+// compile-time constants -- strides, divisions and the LDS carve-up fold away (the generic body spends more instructions on
+// scalar bookkeeping than on the matrix pipe: ~2100 per strip and wave for 72 MFMAs); any other shape runs the same body
+// with the runtime values.
+template <bool FIXED>
 __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a) {
     P2P_DYN_SHARED(unsigned char, sm);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,7 +110,7 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     const int c0 = (g % a.nc) * a.tc; g /= a.nc;
     const int b0 = (g % a.nb) * a.tb; g /= a.nb;
     const int a0 = g * a.ta;
-    const int TA = a.ta, TB = a.tb, TC = a.tc, TD = a.td, P = a.P;
+    const int TA = a.ta, TB = FIXED ? 5 : a.tb, TC = FIXED ? 8 : a.tc, TD = FIXED ? 40 : a.td, P = FIXED ? 44 : a.P;
     const int XROWS = TC + 4, HROWS = TC + 2;
     const int HN = max(HROWS * P, ((HROWS * P + 63) >> 6) * 64) + 2;      // whole layer-1 tiles fit (their tail rows store zeros)
     const int XPLANE = (9 * XROWS * P * 2 + 8 + 15) & ~15;   // bytes of one fp16 plane of the staged input (+ the window overrun of its
@@ -92,9 +123,10 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     unsigned char *Hs = sm + 2 * XPLANE;
     unsigned char *W2s = Hs + 2 * HPLANE;                    // layer-2 B fragments
     float *Ya = (float *)(W2s + NCF_W2_BYTES);
+    float *C1 = Ya + 3 * YSLOT;                              // [16] scale, [16] bias of layer 1's epilogue (16-byte aligned: YSLOT % 4 == 0)
     const size_t nB = (size_t)a.d2 * a.d3;
 
-    // weights of this branch -> registers (they are the B operands of every MFMA of the kernel)
+    // weights of this branch -> registers (layer 1: the A operands of its MFMAs)
     const unsigned char *wb = a.w + (size_t)br * NCF_BRANCH_BYTES;
     nf4 w1[7][2];
 #pragma unroll
@@ -117,102 +149,124 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     const int E = min(max(xeb - 126, 0), 100);
     const float up = __int_as_float((127 + E) << 23), down = __int_as_float((127 - E) << 23);
     const float xscale = 4096.0f * down;
-    const float s1o = cf[lane & 15] * up, b1o = cf[16 + (lane & 15)], hscale = cf[32] * down, yun = cf[33] * up;
+    const float yun = cf[33] * up;
+    if (tid < 16) {      // relu(acc * s1 + b1) * hscale = relu(acc * (s1 hscale) + b1 hscale): layer 1's epilogue constants per channel
+        const float hscale = cf[32] * down;
+        C1[tid] = cf[tid] * up * hscale;
+        C1[16 + tid] = cf[16 + tid] * hscale;
+    }
 
     for (int i = tid; i < 3 * YSLOT; i += NCF_THREADS) Ya[i] = 0.f;
     for (int i = tid; i < 2 * 2 * 2; i += NCF_THREADS) {     // the pad slots before and after the hidden positions stay zero
         const int pl = i >> 2, kh = (i >> 1) & 1, end = i & 1;
         *(nf4 *)(Hs + pl * HPLANE + kh * HKH + (end ? (HN - 1) * 16 : 0)) = (nf4){0.f, 0.f, 0.f, 0.f};
     }
-    __syncthreads();
 
     const int a_hi = min(a0 + TA, a.d0);                     // outputs of the tile: [a0, a_hi)
     const int ap_first = max(a0 - 1, 0), ap_last = min(a0 + TA, a.d0 - 1);
     const int bp_first = max(b0 - 1, 0), bp_last = min(b0 + TB, a.d1 - 1);
 
+    // relu(sum + b2) of the finished output slice aout -> Y; every cell read is reset for the slice that re-uses the slot (the
+    // pad cells of a row are never read, so they need no reset).  No barrier of its own: it runs at the top of the strip after
+    // the slice's last contribution (behind that strip's closing barrier), and the next layer-2 pass that touches the slot
+    // again is behind the barrier between this strip's two layers.
     auto flush = [&](int aout) {
-        // relu(sum + b2) of output slice aout -> Y; the slot becomes zero again
-        __syncthreads();
         float *slot = Ya + (aout % 3) * YSLOT;
         for (int r = wave; r < TB * TC; r += NCF_WAVES) {
             const int bb = r / TC, ro = r - bb * TC;
             const int ib = b0 + bb, ic = c0 + ro, id = dt0 + lane;
-            if (lane < TD && ib < a.d1 && ic < a.d2 && id < a.d3) {
-                const float v = fmaxf(slot[bb * YROW + ro * P + lane + 1] + a.b2, 0.f);
-                float *dst = Y + ((size_t)aout * a.d1 + ib) * nB + (size_t)ic * a.d3 + id;
-                if (plain) *dst = v; else unsafeAtomicAdd(dst, v);
+            if (lane < TD) {
+                float *cell = slot + bb * YROW + ro * P + lane + 1;
+                const float v = fmaxf(*cell + a.b2, 0.f);
+                *cell = 0.f;
+                if (ib < a.d1 && ic < a.d2 && id < a.d3) {
+                    float *dst = Y + ((size_t)aout * a.d1 + ib) * nB + (size_t)ic * a.d3 + id;
+                    if (plain) *dst = v; else unsafeAtomicAdd(dst, v);
+                }
             }
         }
-        __syncthreads();
-        for (int i = tid; i < YSLOT; i += NCF_THREADS) slot[i] = 0.f;
     };
 
-    // The strips (a', b') in order, a' outer.  The input rows of the NEXT strip are fetched into registers while the current
-    // one is computed (their latency is a microsecond).  Row addresses are wave-uniform (scalar base + the lane's clamped
-    // column), everything that does not depend on the strip is worked out once, here.
-    constexpr int NCF_XJ = 3;                                // input rows per wave and plane: (TC + 4) / 4 <= 3
+    // ---- S1: this lane's pair of columns of a staged row (strip-independent)
     const int nbp = bp_last - bp_first + 1, nstrips = (ap_last - ap_first + 1) * nbp;
-    float xv[9 * NCF_XJ];
-    unsigned xok_lo = 0, xok_hi = 0;                         // bit (pl9 * 4 + j): that row of the fetched strip is inside the volume
-    const bool okd = lane < P && dt0 - 2 + lane >= 0 && dt0 - 2 + lane < a.d3;
-    // 32-bit element offsets (a volume has < 2^31 cells): row part = clamped c row * d3 + the lane's clamped column (does
-    // not depend on the strip), plane part = clamped (a, b) * strides (three values each per strip, scalar)
-    const int sB = (int)nB, sA = a.d1 * sB;
-    int rowoff[NCF_XJ];
-    unsigned okc = 0;
+    const int sB = (int)nB, sA = a.d1 * sB;                  // 32-bit element offsets (a volume has < 2^31 cells)
+    const int cp = lane & 31, rh = lane >> 5;
+    const int dcol = dt0 - 2 + 2 * cp;
+    const int coff0 = clampi(dcol, 0, a.d3 - 1), coff1 = clampi(dcol + 1, 0, a.d3 - 1);
+    const bool okd0 = 2 * cp < P && dcol >= 0 && dcol < a.d3, okd1 = 2 * cp < P && dcol + 1 >= 0 && dcol + 1 < a.d3;
+    // item k of this wave = (plane da of the triple (., db), row pair rp); loads are unconditional from clamped addresses, the
+    // zero padding is selected when the value is USED (a load in a branch, or a select right behind it, is waited for on
+    // the spot).  q0v / q1v are the ONLY load destinations inside the strip loop (a second set -- e.g. for the nine planes
+    // of a row start -- makes the compiler wait for every outstanding load, the prefetched ones included, before the first
+    // MFMA of a strip).
+    float q0v[NCF_KRING], q1v[NCF_KRING];
+    // strip-independent parts of this lane's items: source row offset (clamped c row), byte offset of the row pair inside an
+    // LDS plane, validity bits (bit k: the lane stores something for item k; bit 8 + k: its row is inside the volume)
+    int crow[NCF_KRING], lrow[NCF_KRING];
+    unsigned okbits = 0;
 #pragma unroll
-    for (int j = 0; j < NCF_XJ; ++j) {
-        const int xr = wave + NCF_WAVES * j, ic = c0 - 2 + xr;
-        rowoff[j] = clampi(ic, 0, a.d2 - 1) * a.d3 + clampi(dt0 - 2 + lane, 0, a.d3 - 1);
-        okc |= (unsigned)(xr < XROWS && ic >= 0 && ic < a.d2) << j;
+    for (int k = 0; k < NCF_KRING; ++k) {
+        const int it = wave + NCF_WAVES * k, i3 = it / 6, rp = it - 6 * i3;
+        const int xr = 2 * rp + rh, ic = c0 - 2 + xr;
+        crow[k] = clampi(ic, 0, a.d2 - 1) * a.d3;
+        lrow[k] = (xr * P + 2 * cp) * 2;
+        okbits |= (unsigned)(i3 < 3 && xr < XROWS && 2 * cp < P) << k;
+        okbits |= (unsigned)(ic >= 0 && ic < a.d2) << (8 + k);
     }
-    auto fetch = [&](int strip) {
-        const int ap = ap_first + strip / nbp, bp = bp_first + strip % nbp;
-        int pa[3], pb[3];
-        unsigned oka = 0, okb = 0;
+    // a triple = the three planes (pa + i, pb) (along a) or (pa, pb + i) (along b); plane (ia, ib) sits in slot (ia mod 3,
+    // ib mod 3) of the 2-D ring.  Per item (scalars, once per strip): clamped source offset of its plane, inside the volume?,
+    // byte offset of the plane's slot.
+    int isrc[NCF_KRING], idst[NCF_KRING];
+    bool iin[NCF_KRING];
+    auto triple = [&](int pa, int pb, bool along_a) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            pa[i] = clampi(ap + i - 1, 0, a.d0 - 1) * sA;
-            pb[i] = clampi(bp + i - 1, 0, a.d1 - 1) * sB;
-            oka |= (unsigned)(ap + i - 1 >= 0 && ap + i - 1 < a.d0) << i;
-            okb |= (unsigned)(bp + i - 1 >= 0 && bp + i - 1 < a.d1) << i;
+        for (int k = 0; k < NCF_KRING; ++k) {
+            const int i3 = min((wave + NCF_WAVES * k) / 6, 2);
+            const int ia = along_a ? pa + i3 : pa, ib = along_a ? pb : pb + i3;
+            isrc[k] = clampi(ia, 0, a.d0 - 1) * sA + clampi(ib, 0, a.d1 - 1) * sB;
+            iin[k] = ia >= 0 && ia < a.d0 && ib >= 0 && ib < a.d1;
+            idst[k] = (((ia + 3) % 3) * 3 + (ib + 3) % 3) * XROWS * P * 2;
         }
-        unsigned lo = 0, hi = 0;
+    };
+    // the current triple: loads (unconditional, from clamped addresses; the zero padding is selected when the value is used) ...
+    auto ring_load = [&]() {
 #pragma unroll
-        for (int pl9 = 0; pl9 < 9; ++pl9) {
-            const int base = pa[pl9 / 3] + pb[pl9 % 3];
-            const unsigned okab = (oka >> (pl9 / 3)) & (okb >> (pl9 % 3)) & 1u;
+        for (int k = 0; k < NCF_KRING; ++k) {
+            const int src = isrc[k] + crow[k];
+            q0v[k] = X[src + coff0]; q1v[k] = X[src + coff1];
+        }
+    };
+    // ... and their conversion to two fp16 planes of X * 2^12 (adjacent columns packed: one 4-byte store per plane)
+    auto ring_store = [&]() {
 #pragma unroll
-            for (int j = 0; j < NCF_XJ; ++j) {
-                // unconditional load from a clamped address; the zero padding is selected when the value is USED (a load in a
-                // branch, or a select right behind it, is waited for on the spot: dozens of round trips one after the other)
-                xv[pl9 * NCF_XJ + j] = X[base + rowoff[j]];
-                const int bit = pl9 * NCF_XJ + j;
-                const unsigned ok = okab & (okc >> j);
-                if (bit < 32) lo |= ok << bit; else hi |= ok << (bit - 32);
+        for (int k = 0; k < NCF_KRING; ++k) {
+            if ((okbits >> k) & 1u) {
+                const bool inside = iin[k] && ((okbits >> (8 + k)) & 1u);
+                const int dst = idst[k] + lrow[k];
+                const float x0 = (inside && okd0) ? q0v[k] * xscale : 0.f, x1 = (inside && okd1) ? q1v[k] * xscale : 0.f;
+                const unsigned h = npk(x0, x1);
+                *(unsigned *)(Xs + dst) = h;
+                *(unsigned *)(Xs + XPLANE + dst) = npk(x0 - npk_lo(h), x1 - npk_hi(h));
             }
         }
-        xok_lo = okd ? lo : 0u;
-        xok_hi = okd ? hi : 0u;
     };
 
-    // layer 1: this wave's m-tiles (<= 2): store offsets, validity of the 16 accumulator rows of the lane
-    const int l31 = lane & 31, kb5 = lane >> 5, ch = lane & 15, par = (lane >> 4) & 1;
+    // ---- S2 (layer 1): D[row = (parity s, channel o)][column = position q0 + 2 * (lane & 31) + s].  This lane's registers
+    // 4 G + j of an accumulator are s = G >> 1, o = 8 (G & 1) + 4 (lane >> 5) + j: four consecutive channels of ONE position.
+    const int l31 = lane & 31, kb5 = lane >> 5;
     const int nt1 = (HROWS * P + 63) >> 6;
-    unsigned s2ok[2] = {0, 0};
-    int s2dst[2] = {0, 0}, s2qh[2] = {0, 0};
+    int s2qh[2] = {0, 0};
+    unsigned s2ok = 0;                                        // bit 2 u + s: position q0(u) + 2 l31 + s is a cell of the volume
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int t = wave + NCF_WAVES * u, q0 = t * 64;
-        s2qh[u] = min(q0 + 2 * l31, HROWS * P - 2);           // rows past the strip repeat its last row (never stored)
-        const int fl0 = q0 + 8 * kb5 + par;                   // D: row i = (r & 3) + 8 (r >> 2) + 4 kb -> position q0 + 2 i + par
-        s2dst[u] = (ch >> 3) * HKH + (ch & 7) * 2 + 16 + fl0 * 16;     // + 16: position -1 is slot 0
+        s2qh[u] = min(q0 + 2 * l31, HROWS * P - 2);           // columns past the strip repeat its last pair (never stored)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int fl = fl0 + 2 * (r & 3) + 16 * (r >> 2), rowh = fl / P, col = fl - rowh * P;
+        for (int sp = 0; sp < 2; ++sp) {
+            const int fl = q0 + 2 * l31 + sp, rowh = fl / P, col = fl - rowh * P;
             const int ic = c0 - 1 + rowh, id = dt0 + col - 1;
             const bool ok = t < nt1 && rowh < HROWS && col <= TD + 1 && ic >= 0 && ic < a.d2 && id >= 0 && id < a.d3;
-            s2ok[u] |= (unsigned)ok << r;
+            s2ok |= (unsigned)ok << (2 * u + sp);
         }
     }
     // layer 2: hidden offsets of the lane's K block per step
@@ -225,79 +279,116 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     }
     const int nt2 = (TC * P + 15) >> 4;
 
-    if (nstrips > 0) fetch(0);
+    // The strips of the tile in SERPENTINE order: a' rows ascending, b' ascending in even rows (global index a') and descending
+    // in odd ones, so that EVERY step -- along b' inside a row, along a' at a row's end -- brings exactly one new triple of
+    // planes into the 2-D ring (prefetched a phase ahead; a raster order restaged all nine planes at every row start, with
+    // their latency exposed).  The direction depends on the global a' only: an output cell sums its nine contributions in an
+    // order that does not depend on the tile.
+    auto strip_bp = [&](int ap, int j) { return (ap & 1) ? bp_last - j : bp_first + j; };
+    __syncthreads();
+    NT_DECL
+    {
+        const int bq = strip_bp(ap_first, 0);
+        for (int i = 0; i < 3; ++i) {         // all nine planes of the first strip
+            triple(ap_first - 1, bq - 1 + i, true);
+            ring_load();
+            ring_store();
+        }
+    }
+    __syncthreads();
+    NT(0)
+    int pending = -1;                         // output slice whose last contribution the previous strip added
     for (int strip = 0; strip < nstrips; ++strip) {
-        const int ap = ap_first + strip / nbp, bp = bp_first + strip % nbp;
-        // ---------------- S1: the nine input planes around the strip -> two fp16 planes of X * 2^12 in LDS
-#pragma unroll
-        for (int pl9 = 0; pl9 < 9; ++pl9)
-#pragma unroll
-            for (int j = 0; j < NCF_XJ; ++j) {
-                const int xr = wave + NCF_WAVES * j, bit = pl9 * NCF_XJ + j;
-                const bool okv = (bit < 32) ? (xok_lo >> bit) & 1u : (xok_hi >> (bit - 32)) & 1u;
-                const float v = okv ? xv[bit] * xscale : 0.f;
-                const unsigned short h0 = nf2h(v), h1 = nf2h(v - nh2f(h0));
-                // columns (c, c + 1) sit in adjacent lanes: the even lane stores the pair's first plane, the odd lane its second
-                const bool oddl = lane & 1;
-                const unsigned mine = oddl ? h1 : h0, give = oddl ? h0 : h1;
-                const unsigned got = P2P_SWAP_ADJACENT(give);
-                if (xr < XROWS && lane < P)
-                    *(unsigned *)(Xs + (oddl ? XPLANE : 0) + ((pl9 * XROWS + xr) * P + (lane & ~1)) * 2) = oddl ? (got | mine << 16) : (mine | got << 16);
-            }
-        __syncthreads();
-        if (strip + 1 < nstrips) fetch(strip + 1);
+        const int row = strip / nbp, j = strip - row * nbp;
+        const int ap = ap_first + row, bp = strip_bp(ap, j);
+        const bool more = strip + 1 < nstrips, same_row = j + 1 < nbp;
+        const int dir = (ap & 1) ? -1 : 1;
+        // the new triple of the next strip: planes (ap - 1 .. ap + 1, b' + 2 dir) inside a row, (ap + 2, b' - 1 .. b' + 1) at its end
+        const int npa = same_row ? ap - 1 : ap + 2, npb = same_row ? bp + 2 * dir : bp - 1;
+        if (pending >= 0) flush(pending);
+        pending = -1;
+        NT(5)
+        triple(npa, npb, same_row);
+        if (more) ring_load();                                // in flight during both layers of this strip
         // ---------------- S2: layer 1 -> hidden planes
-#ifndef NCF_SKIP_S2                     // timing experiments (wrong results): NCF_SKIP_S2 / _S3 / _S2EPI drop one part
         {
-            // both m-tiles of the wave together (independent accumulators, the weights are shared); a wave with one tile
-            // multiplies a clamped copy of it -- it would wait at the barrier for the others anyway
+            // ring slots of the planes a' - 1 .. a' + 1 and b' - 1 .. b' + 1 (element offsets)
+            const int sa0 = ((ap + 2) % 3) * 3 * XROWS * P, sa1 = ((ap + 3) % 3) * 3 * XROWS * P, sa2 = ((ap + 4) % 3) * 3 * XROWS * P;
+            const int sl0 = ((bp + 2) % 3) * XROWS * P, sl1 = ((bp + 3) % 3) * XROWS * P, sl2 = ((bp + 4) % 3) * XROWS * P;
+            auto xoff = [&](int gq) {                         // tap group (da, db, dc) -> element offset of its plane row
+                const int da = gq / 9, db = (gq / 3) % 3, dc = gq % 3;
+                return (da == 0 ? sa0 : da == 1 ? sa1 : sa2) + (db == 0 ? sl0 : db == 1 ? sl1 : sl2) + dc * P;
+            };
+            // both position tiles of the wave together (independent accumulators, the weights are shared); a wave with one
+            // tile multiplies a clamped copy of it -- it would wait at the barrier for the others anyway
             f32x16 acc[2] = {{0}, {0}};
-#pragma unroll
-            for (int sl = 0; sl < 7; ++sl) {
+            // the X fragments of slab sl + 1 are read while the six MFMAs of slab sl issue; sched_barrier pins that order (left to
+            // itself the compiler re-uses one set of fragment registers and waits for every read right in front of its MFMA:
+            // ~4000 of a strip's ~5800 layer-1 cycles were LDS latency)
+            nf4 xv[2][2][2];                                   // [buffer][tile][plane]
+            auto frags = [&](int sl, nf4 (&d)[2][2]) {
                 // the lane's two tap groups of this slab: g = 4 * sl + 2 * kb + {0, 1}; group 27 does not exist (zero weights)
-                const int g0 = 4 * sl + 2 * kb5, g1 = min(g0 + 1, 26);
-                const int o0 = ((g0 / 3) * XROWS + g0 % 3) * P, o1 = ((g1 / 3) * XROWS + g1 % 3) * P;
-                nf4 av[2][2];
+                // (the four offsets are made opaque scalars: otherwise the select over the lane half becomes a lane-indexed lookup
+                // in a private array = scratch memory)
+                int oa0 = xoff(4 * sl), oa1 = xoff(4 * sl + 1), ob0 = xoff(4 * sl + 2), ob1 = xoff(min(4 * sl + 3, 26));
+                P2P_OPAQUE_S(oa0); P2P_OPAQUE_S(oa1); P2P_OPAQUE_S(ob0); P2P_OPAQUE_S(ob1);
+                const int o0 = kb5 ? ob0 : oa0, o1 = kb5 ? ob1 : oa1;
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int p = 0; p < 2; ++p) {
                         const unsigned *x0 = (const unsigned *)(Xs + p * XPLANE + (o0 + s2qh[u]) * 2);
                         const unsigned *x1 = (const unsigned *)(Xs + p * XPLANE + (o1 + s2qh[u]) * 2);
-                        av[u][p] = (nf4){__uint_as_float(x0[0]), __uint_as_float(x0[1]), __uint_as_float(x1[0]), __uint_as_float(x1[1])};
+                        d[u][p] = (nf4){__uint_as_float(x0[0]), __uint_as_float(x0[1]), __uint_as_float(x1[0]), __uint_as_float(x1[1])};
                     }
-                acc[0] = NCF_MFMA32(av[0][1], w1[sl][0], acc[0]); acc[1] = NCF_MFMA32(av[1][1], w1[sl][0], acc[1]);
-                acc[0] = NCF_MFMA32(av[0][0], w1[sl][1], acc[0]); acc[1] = NCF_MFMA32(av[1][0], w1[sl][1], acc[1]);
-                acc[0] = NCF_MFMA32(av[0][0], w1[sl][0], acc[0]); acc[1] = NCF_MFMA32(av[1][0], w1[sl][0], acc[1]);
+            };
+            frags(0, xv[0]);
+#pragma unroll
+            for (int sl = 0; sl < 7; ++sl) {
+                nf4 (&c)[2][2] = xv[sl & 1];
+                if (sl < 6) frags(sl + 1, xv[(sl + 1) & 1]);
+                acc[0] = NCF_MFMA32(w1[sl][0], c[0][1], acc[0]); acc[1] = NCF_MFMA32(w1[sl][0], c[1][1], acc[1]);
+                acc[0] = NCF_MFMA32(w1[sl][1], c[0][0], acc[0]); acc[1] = NCF_MFMA32(w1[sl][1], c[1][0], acc[1]);
+                acc[0] = NCF_MFMA32(w1[sl][0], c[0][0], acc[0]); acc[1] = NCF_MFMA32(w1[sl][0], c[1][0], acc[1]);
+                // order inside the slab: its first MFMA leads, the address arithmetic and the eight reads of the next slab's
+                // fragments follow in the shadow of the MFMAs (a matrix instruction occupies its pipe for 32 cycles, the
+                // vector ALU is free meanwhile)
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-#ifndef NCF_SKIP_S2EPI
-            // bias, ReLU, zero outside the volume, scale, split.  Channel pairs (o, o + 1) sit in adjacent lanes: the even lane
-            // stores the pair's first plane, the odd lane its second plane -- one 4-byte store per lane and row instead of two
-            // 2-byte ones
-            const bool odd = ch & 1;
-            const float s1h = s1o * hscale, b1h = b1o * hscale;      // relu(x) * 2^k = relu(x * 2^k)
+            // bias, ReLU, zero outside the volume, scale, split: four consecutive channels of a position per register group
+            // -> one 8-byte store per plane
+            const nf4 sc0 = *(const nf4 *)(C1 + 4 * kb5), sc1 = *(const nf4 *)(C1 + 8 + 4 * kb5);
+            const nf4 bi0 = *(const nf4 *)(C1 + 16 + 4 * kb5), bi1 = *(const nf4 *)(C1 + 24 + 4 * kb5);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (wave + NCF_WAVES * u >= nt1) break;               // (wave-uniform) the clamped copy is not stored
-                unsigned char *hdst = Hs + s2dst[u] + (odd ? HPLANE - 2 : 0);      // the pair's first channel in this lane's plane
+                const int q0 = (wave + NCF_WAVES * u) * 64;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float h = ((s2ok[u] >> r) & 1u) ? fmaxf(fmaf(acc[u][r], s1h, b1h), 0.f) : 0.f;
-                    const unsigned short h0 = nf2h(h), h1 = nf2h(h - nh2f(h0));
-                    const unsigned mine = odd ? h1 : h0, give = odd ? h0 : h1;       // keep the half of my plane, hand the other to the partner
-                    const unsigned got = P2P_SWAP_ADJACENT(give);
-                    const unsigned word = odd ? (got | mine << 16) : (mine | got << 16);
-                    *(unsigned *)(hdst + (2 * (r & 3) + 16 * (r >> 2)) * 16) = word;
+                for (int G = 0; G < 4; ++G) {
+                    const int sp = G >> 1, kh = G & 1;
+                    const bool okq = (s2ok >> (2 * u + sp)) & 1u;
+                    const nf4 sc = kh ? sc1 : sc0, bi = kh ? bi1 : bi0;
+                    float h[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) h[j] = okq ? fmaxf(fmaf(acc[u][4 * G + j], sc[j], bi[j]), 0.f) : 0.f;
+                    const unsigned pa = npk(h[0], h[1]), pb = npk(h[2], h[3]);
+                    const unsigned ra = npk(h[0] - npk_lo(pa), h[1] - npk_hi(pa)), rb = npk(h[2] - npk_lo(pb), h[3] - npk_hi(pb));
+                    unsigned char *dst = Hs + kh * HKH + (q0 + 2 * l31 + sp + 1) * 16 + 8 * kb5;      // + 1: position -1 is slot 0
+                    *(nf2 *)dst = (nf2){__uint_as_float(pa), __uint_as_float(pb)};
+                    *(nf2 *)(dst + HPLANE) = (nf2){__uint_as_float(ra), __uint_as_float(rb)};
                 }
             }
-#else
-            if (acc[0][0] == 12345.f || acc[1][0] == 12345.f) Hs[tid] = 1;
-#endif
         }
-#endif
+        NT(1)
         __syncthreads();
+        NT(2)
         // ---------------- S3: layer 2, contributions of the strip to the 3 x 3 output planes around it
-#ifndef NCF_SKIP_S3
         {
             const int n = lane & 15, da = n / 3, db = n - 3 * da;
             const int aout = ap - da + 1, bout = bp - db + 1;
@@ -310,21 +401,23 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
                 const unsigned char *ha = Hs + min(qa + row16, TC * P - 1) * 16, *hb = Hs + min(qb + row16, TC * P - 1) * 16;
                 const unsigned char *wl = W2s + lane * 16;
                 nf4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
-                nf4 a0v = *(const nf4 *)(ha + s3off[0]), a1v = *(const nf4 *)(ha + s3off[0] + HPLANE);
-                nf4 b0v = *(const nf4 *)(hb + s3off[0]), b1v = *(const nf4 *)(hb + s3off[0] + HPLANE);
-                nf4 w0v = *(const nf4 *)wl, w1v = *(const nf4 *)(wl + 1024);
+                // the fragments of step st + 1 are read while the six MFMAs of step st issue (order pinned by sched_barrier)
+                nf4 fr[2][6];                                  // [buffer][a plane 0, a plane 1, b plane 0, b plane 1, w plane 0, w plane 1]
+                auto frags3 = [&](int st, nf4 (&d)[6]) {
+                    d[0] = *(const nf4 *)(ha + s3off[st]); d[1] = *(const nf4 *)(ha + s3off[st] + HPLANE);
+                    d[2] = *(const nf4 *)(hb + s3off[st]); d[3] = *(const nf4 *)(hb + s3off[st] + HPLANE);
+                    d[4] = *(const nf4 *)(wl + st * 2048); d[5] = *(const nf4 *)(wl + st * 2048 + 1024);
+                };
+                frags3(0, fr[0]);
 #pragma unroll
                 for (int st = 0; st < 5; ++st) {
-                    nf4 na0 = a0v, na1 = a1v, nb0 = b0v, nb1 = b1v, nw0 = w0v, nw1 = w1v;
-                    if (st < 4) {
-                        na0 = *(const nf4 *)(ha + s3off[st + 1]); na1 = *(const nf4 *)(ha + s3off[st + 1] + HPLANE);
-                        nb0 = *(const nf4 *)(hb + s3off[st + 1]); nb1 = *(const nf4 *)(hb + s3off[st + 1] + HPLANE);
-                        nw0 = *(const nf4 *)(wl + (st + 1) * 2048); nw1 = *(const nf4 *)(wl + (st + 1) * 2048 + 1024);
-                    }
-                    accA = NCF_MFMA16(a1v, w0v, accA); accB = NCF_MFMA16(b1v, w0v, accB);
-                    accA = NCF_MFMA16(a0v, w1v, accA); accB = NCF_MFMA16(b0v, w1v, accB);
-                    accA = NCF_MFMA16(a0v, w0v, accA); accB = NCF_MFMA16(b0v, w0v, accB);
-                    a0v = na0; a1v = na1; b0v = nb0; b1v = nb1; w0v = nw0; w1v = nw1;
+                    nf4 (&c)[6] = fr[st & 1];
+                    if (st < 4) frags3(st + 1, fr[(st + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    accA = NCF_MFMA16(c[1], c[4], accA); accB = NCF_MFMA16(c[3], c[4], accB);
+                    accA = NCF_MFMA16(c[0], c[5], accA); accB = NCF_MFMA16(c[2], c[5], accB);
+                    accA = NCF_MFMA16(c[0], c[4], accA); accB = NCF_MFMA16(c[2], c[4], accB);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 // D: row 4 kb + r = output position q + 4 kb + r, column n = plane (da, db).  Plain read-add-write: inside a
                 // strip every accumulator word is touched by exactly one lane (other tiles = other positions, other lanes =
@@ -358,10 +451,23 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
                 }
             }
         }
-#endif
-        if (bp == bp_last && ap - 1 >= a0) flush(ap - 1);
+        NT(3)
+        // ---------------- S1 of the next strip, behind this strip's layer 2 (layer 1 of this strip is done with the planes)
+        if (more) ring_store();
+        NT(4)
+        if (!same_row && ap - 1 >= a0) pending = ap - 1;       // output slice ap - 1 is complete once hidden slice ap is done
+        __syncthreads();
+        NT(6)
     }
+    if (pending >= 0) flush(pending);
     if (nstrips > 0 && ap_last < a_hi && ap_last >= a0) flush(ap_last);      // the volume ends inside the tile: its last slice has no slice above
+#ifdef NCF_TIMING
+    if (blockIdx.x == 5 && blockIdx.y == 0 && lane == 0) {       // (overwrites a few output cells: timing builds only)
+        __syncthreads();
+        for (int i = 0; i < 8; ++i) Y[wave * 8 + i] = (float)nt_[i];
+        Y[32] = (float)nstrips;
+    }
+#endif
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------
@@ -496,10 +602,14 @@ int launch_nc_fused(const float *X, float *Y, float *Y2, size_t stride, int pair
     P2P_HIP_CHECK(hipGetDevice(&dev));
     static bool attr_set[64] = {false};
     if (dev >= 64 || !attr_set[dev]) {
-        P2P_HIP_CHECK(hipFuncSetAttribute((const void *)nc_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        P2P_HIP_CHECK(hipFuncSetAttribute((const void *)nc_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        P2P_HIP_CHECK(hipFuncSetAttribute((const void *)nc_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(nc_fused_kernel, dim3(a.na * a.nb * a.nc * a.nd, 2, pairs), dim3(NCF_THREADS), lds, stream, a);
+    if (a.tb == 5 && a.tc == 8 && a.td == 40 && a.P == 44)
+        hipLaunchKernelGGL(nc_fused_kernel<true>, dim3(a.na * a.nb * a.nc * a.nd, 2, pairs), dim3(NCF_THREADS), lds, stream, a);
+    else
+        hipLaunchKernelGGL(nc_fused_kernel<false>, dim3(a.na * a.nb * a.nc * a.nd, 2, pairs), dim3(NCF_THREADS), lds, stream, a);
     return check_launch("nc_fused_kernel");
 }
 
