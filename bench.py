@@ -167,7 +167,7 @@ def parity_check(net, ckpt, batch, cpu_pairs, cfg, pairs=None):
     "every row decidable in fp32 is equal".  The proposals of such a pair differ legitimately and its fine stage is
     compared on the kernel's own proposals."""
     from oracle import p2p_oracle as orc
-    from oracle.error_model import ErrorModel, assert_decidable_rows, differing_rows_are_near_ties
+    from oracle.error_model import ErrorModel, assert_decidable_rows, differing_rows_are_near_ties, differing_rows_are_near_ties_local
     seed = 4242
     np.random.seed(seed)
     rng = np.random.RandomState(seed)
@@ -196,10 +196,13 @@ def parity_check(net, ckpt, batch, cpu_pairs, cfg, pairs=None):
             out["pairs_with_differing_rows"] += int(ndiff > 0)
             if ndiff:
                 try:
-                    em = ErrorModel(p1[4], p2[4], ckpt["state_dict"], KSIZE)
-                    em.check(corr, "oracle fp32 volume")
-                    _, worst = differing_rows_are_near_ties(got_rows, rows, em)
-                    assert_decidable_rows(got_rows, em)
+                    if cfg["H"] > 480:       # the full fp64 model costs minutes at 960x1280: evaluated where the differing rows need it
+                        _, worst = differing_rows_are_near_ties_local(got_rows, rows, p1[4], p2[4], ckpt["state_dict"], KSIZE)
+                    else:
+                        em = ErrorModel(p1[4], p2[4], ckpt["state_dict"], KSIZE)
+                        em.check(corr, "oracle fp32 volume")
+                        _, worst = differing_rows_are_near_ties(got_rows, rows, em)
+                        assert_decidable_rows(got_rows, em)
                     out["worst_gap_over_fp32_error_bound"] = max(out["worst_gap_over_fp32_error_bound"], worst)
                 except AssertionError as e:
                     out["coarse_rows_differing_decidable"] += ndiff
@@ -426,6 +429,50 @@ def stream_mode(args, net, cfg, mode, rank, world, dev, dist):
                     "pyramids (the stand-in for the backbone producer) and every exchange"}
 
 
+def _sync(dev):
+    if torch.device(dev).type == "cuda":
+        torch.cuda.synchronize()
+
+
+def timed_steps(run, nsteps, with_gather, rank, world, pairs_per_step, dev, dist):
+    """The timed region of the weak-scaling contract: barrier + synchronize, `run(nsteps)` on this rank, the final gather
+    of the match arrays (the only inter-GPU exchange of the path), barrier + synchronize.  -> elapsed (this rank's clock
+    over the whole region), local_elapsed (up to the end of this rank's own steps), the regress launch events, rows gathered."""
+    from patch2pix_amd import ops
+    from patch2pix_amd.gather import gather_matches, pack_results
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        _sync(dev)
+
+    barrier()
+    ops.regress_events = []
+    t0 = time.perf_counter()
+    results = run(nsteps)
+    _sync(dev)
+    local_elapsed = time.perf_counter() - t0
+    nrows = None
+    if with_gather:
+        all_rows, all_ids = gather_matches(*pack_results(results, rank, world, pairs_per_step, device=dev))
+        nrows = all_rows.shape[0]
+        assert all_ids.dtype == torch.int64 and all_ids.shape[0] == nrows
+    barrier()
+    elapsed = time.perf_counter() - t0
+    events, ops.regress_events = ops.regress_events, None
+    return {"elapsed": elapsed, "local_elapsed": local_elapsed, "events": events, "nrows": nrows}
+
+
+def exchange_rank_stats(dist, dev, world, values):
+    """all_gather of a few float64 numbers per rank -> list (by rank) of lists."""
+    if dist is None:
+        return [list(values)]
+    t = torch.tensor(values, device=dev, dtype=torch.float64)
+    allt = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(allt, t)
+    return [[float(v) for v in x] for x in allt]
+
+
 def main():
     args = parse()
     cfg = dict(CONFIGS[args.config])
@@ -454,7 +501,6 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from patch2pix_amd import ops
-    from patch2pix_amd.gather import gather_matches, pack_results
     from patch2pix_amd.utils import synthetic
     from patch2pix_amd.utils.eval import model_helper
 
@@ -481,27 +527,9 @@ def main():
     runner = Runner(net, batches, PTMAX, overlap=bool(args.overlap), depth=args.depth)
     run = runner.run
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     def timed(nsteps, with_gather):
-        barrier()
-        ops.regress_events = []
-        t0 = time.perf_counter()
-        results = run(nsteps)
-        nrows = None
-        if with_gather:
-            # final gather of the match arrays (the only inter-GPU exchange of the path)
-            all_rows, all_ids = gather_matches(*pack_results(results, rank, world, B, device=dev))
-            nrows = all_rows.shape[0]
-            assert all_ids.dtype == torch.int64 and all_ids.shape[0] == nrows
-        barrier()
-        elapsed = time.perf_counter() - t0
-        events = ops.regress_events
-        ops.regress_events = None
-        return elapsed, events, nrows
+        t = timed_steps(run, nsteps, with_gather, rank, world, B, dev, dist)
+        return t["elapsed"], t["events"], t["nrows"], t["local_elapsed"]
 
     with torch.no_grad():
         # untimed spin-up: a fresh box needs ~1 s of work before clocks / allocator / page cache settle
@@ -511,12 +539,13 @@ def main():
             run(2)
             torch.cuda.synchronize()
         run(args.warmup)
-        elapsed, events, nrows = timed(args.steps, True)
+        elapsed, events, nrows, local_elapsed = timed(args.steps, True)
     assert nrows == world * args.steps * B * PTMAX * cfg["panc"]
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    # every rank's own numbers (weak scaling: each ran its own K steps): its rate up to the end of its own work, and the
+    # roofline of its regress launches -- gathered so that rank 0 can print them; `elapsed` = the slowest rank's time
+    my_roof = roofline_of(mode, events)
+    per_rank = exchange_rank_stats(dist, dev, world, [elapsed, args.steps * B / local_elapsed, my_roof["avg_launch_ms"], my_roof["frac"]])
+    elapsed = max(r[0] for r in per_rank)
 
     value = world * args.steps * B / elapsed
     if rank == 0:
@@ -537,6 +566,9 @@ def main():
                              "note": "compulsory bytes of the whole path per pair (SURVEY 8d) x pairs/s per GPU; the path "
                                      "is MFMA-bound (4300 flop/B), so this fraction is << 1 by construction"},
             "per_gpu_pairs_per_s": value / world,
+            "per_rank_pairs_per_s": [r[1] for r in per_rank],
+            "per_rank_regress_launch_ms": [r[2] for r in per_rank],
+            "per_rank_roofline_frac": [r[3] for r in per_rank],
             "host": {"threads_pinned_to_gpu_local_cpus": len(pinned_cpus) if pinned_cpus else 0,
                      "torch_cpu_threads": torch.get_num_threads(), "usable_cores": usable_cores(),
                      "coarse_stages_enqueued_ahead": args.depth},
@@ -556,7 +588,7 @@ def main():
                 with torch.no_grad():
                     run(2)
                     n2 = max(3, args.steps // 4)
-                    e2, ev2, _ = timed(n2, False)
+                    e2, ev2, _, _ = timed(n2, False)
                 r2 = roofline_of(m2, ev2)
                 other[m2] = {"value": n2 * B / e2, "unit": "pairs/s", "dtype": MODES[m2]["dtype"],
                              "roofline_frac": r2["frac"], "achieved": r2["achieved"], "peak": r2["peak"],

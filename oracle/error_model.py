@@ -200,3 +200,109 @@ def differing_rows_are_near_ties(rows_got, rows_ref, model, upsample=8, tol=NEAR
                                             f"{float(ratio.max()):.2f}x the fp32 error bound of the two candidates (accepted: {tol})")
         worst = max(worst, float(ratio.max()))
     return int(bad.numel()), worst
+
+
+class LocalErrorModel:
+    """The same fp64 evaluation + fp32 error bound, evaluated only where a differing row needs it.  At 960x1280 the pooled
+    volume has 23 M cells and the full model costs minutes of fp64 4-D convolutions; a row's two candidates need the
+    consensus output only on one A row / B column of the volume each (MutualMatching, ncn/model.py:157-176, divides by
+    the maxima of exactly those), and a cell of the consensus output depends on a 5^4 neighbourhood of its input
+    (conv4d.py:12-74 twice).  The pooled correlation and the first MutualMatching are evaluated in full (chunked GEMMs and
+    elementwise work), the two consensus layers on crops [a-2:a+3, b-2:b+3, :, :] / [:, :, c-2:c+3, d-2:d+3]."""
+
+    def __init__(self, feat_a, feat_b, state_dict, ksize=2, lam=1.0, chunk=8):
+        assert ksize > 1, "the local model is for the pooled (ksize 2) volumes of large images"
+        self.ncn, _, _ = orc.split_params(state_dict, torch.float64)
+        self.lam, self.ksize = lam, ksize
+        fa, fb = feat_a.double(), feat_b.double()
+        self.na, self.nb = orc.l2_normalize(fa, 0), orc.l2_normalize(fb, 0)
+        self.eps_c = _eps(fa.shape[0], lam) + 2 * (0.5 * _eps(fa.shape[0], lam) + 3 * U)
+        k = ksize
+        c_, ha, wa = fa.shape
+        _, hb, wb = fb.shape
+        nb_flat, nb_abs = self.nb.reshape(c_, -1), self.nb.abs().reshape(c_, -1)
+        p = torch.empty(ha // k, wa // k, hb // k, wb // k, dtype=torch.float64)
+        ep = torch.empty_like(p)
+        for r0 in range(0, ha // k, chunk):           # pooled rows r0 .. r1 of A: k * (r1 - r0) feature rows
+            r1 = min(r0 + chunk, ha // k)
+            xa = self.na[:, k * r0:k * r1].reshape(c_, -1)
+            for src, dst, xb in ((xa, p, nb_flat), (xa.abs(), ep, nb_abs)):
+                cc = (src.t() @ xb).reshape(r1 - r0, k, wa // k, k, hb // k, k, wb // k, k)
+                dst[r0:r1] = cc.permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(r1 - r0, wa // k, hb // k, wb // k, k ** 4).amax(-1)
+        ep *= self.eps_c
+        self.x, self.ex = _mm_err(p, ep)
+        self.shape = tuple(p.shape)
+        self._rows, self._cols = {}, {}
+
+    def corr_at(self, ia, ib):
+        """fp64 correlation and fp32 bound of one full-resolution position pair (relocalisation near-ties)."""
+        va, vb = self.na[:, ia[0], ia[1]], self.nb[:, ib[0], ib[1]]
+        return float((va * vb).sum()), self.eps_c * float((va * vb).abs().sum())
+
+    def _consensus_crop(self, sl):
+        """NeighConsensus.forward (both branches) and its bound on a crop of the MutualMatching output."""
+        x, ex = self.x[sl].contiguous(), self.ex[sl].contiguous()
+        y1, e1 = _net_err(x, ex, self.ncn, self.lam)
+        y2, e2 = _net_err(x.permute(2, 3, 0, 1).contiguous(), ex.permute(2, 3, 0, 1).contiguous(), self.ncn, self.lam)
+        y = y1 + y2.permute(2, 3, 0, 1)
+        return y, e1 + e2.permute(2, 3, 0, 1) + U * y.abs()
+
+    def _row(self, a, b):                       # y[a, b, :, :] and its bound
+        if (a, b) not in self._rows:
+            a0, b0 = max(a - 2, 0), max(b - 2, 0)
+            y, e = self._consensus_crop((slice(a0, a + 3), slice(b0, b + 3)))
+            self._rows[(a, b)] = (y[a - a0, b - b0], e[a - a0, b - b0])
+        return self._rows[(a, b)]
+
+    def _col(self, c, d):                       # y[:, :, c, d] and its bound
+        if (c, d) not in self._cols:
+            c0, d0 = max(c - 2, 0), max(d - 2, 0)
+            y, e = self._consensus_crop((slice(None), slice(None), slice(c0, c + 3), slice(d0, d + 3)))
+            self._cols[(c, d)] = (y[:, :, c - c0, d - d0], e[:, :, c - c0, d - d0])
+        return self._cols[(c, d)]
+
+    def cell(self, a, b, c, d):
+        """(Z, E) of the final volume at one cell: the second MutualMatching on the consensus output."""
+        yr, er = self._row(a, b)
+        yc, ec = self._col(c, d)
+        y, ey = yr[c, d], er[c, d]
+        r, cm = yr.max() + 1e-5, yc.max() + 1e-5
+        z = y * ((y / r) * (y / cm))
+        e = 3 * y * y / (r * cm) * ey + z.abs() * (er.max() / r + ec.max() / cm + 6 * U)
+        return float(z), float(e)
+
+
+def differing_rows_are_near_ties_local(rows_got, rows_ref, feat_a, feat_b, state_dict, ksize=2, upsample=8, tol=NEAR_TIE_TOL,
+                                       volume_got=None, check_limit=CHECK_LIMIT):
+    """`differing_rows_are_near_ties` through the LocalErrorModel (built only when a row differs): the two candidates of a
+    differing row must be closer in fp64 than `tol` x their fp32 bounds; with `volume_got` (the kernel's final volume) the
+    kernel's values at the visited cells must also lie within `check_limit` x the bound of the fp64 values.
+    Returns (number of differing rows, worst gap / bound ratio)."""
+    rows_got, rows_ref = torch.as_tensor(rows_got), torch.as_tensor(rows_ref)
+    bad = torch.nonzero((rows_got != rows_ref).any(dim=1)).flatten()
+    if bad.numel() == 0:
+        return 0, 0.0
+    model = LocalErrorModel(feat_a, feat_b, state_dict, ksize)
+    k, worst = ksize, 0.0
+    nB = model.shape[2] * model.shape[3]
+    for r in bad.tolist():
+        g, f = _cells(rows_got[r:r + 1], k, upsample), _cells(rows_ref[r:r + 1], k, upsample)
+        cg, cr = tuple(int(v[0]) for v in g), tuple(int(v[0]) for v in f)
+        if cg == cr:                           # same pooled cell, another relocalisation: the two full-resolution correlations
+            pg, pr = (rows_got[r] - upsample // 2) // upsample, (rows_ref[r] - upsample // 2) // upsample   # (jA, iA, jB, iB)
+            (vg, eg), (vr, er) = (model.corr_at((int(q[1]), int(q[0])), (int(q[3]), int(q[2]))) for q in (pg, pr))
+            gap, bound = abs(vg - vr), eg + er
+        else:
+            same_query = (cg[2:] == cr[2:]) if r < nB else (cg[:2] == cr[:2])
+            assert same_query, f"row {r}: the differing row does not even belong to the same query cell"
+            (zg, eg), (zr, er) = model.cell(*cg), model.cell(*cr)
+            gap, bound = abs(zg - zr), eg + er
+            if volume_got is not None:
+                for cell, z, e in ((cg, zg, eg), (cr, zr, er)):
+                    err = abs(float(volume_got[cell]) - z)
+                    assert err <= check_limit * e, (f"row {r}: the kernel's volume at {cell} is {err:.2e} from the fp64 value "
+                                                    f"({err / e:.2f} of the fp32 bound, limit {check_limit})")
+        assert gap <= tol * bound, (f"row {r} differs and is no near-tie: fp64 gap {gap:.3e} = {gap / max(bound, 1e-300):.2f} of the "
+                                    f"fp32 error bound of the two candidates (accepted: {tol})")
+        worst = max(worst, gap / max(bound, 1e-300))
+    return int(bad.numel()), worst

@@ -94,6 +94,8 @@ class ResNet34(nn.Module):
         sig = self._hip_signature(device)
         if getattr(self, "_hip_sig", None) != sig:
             def pack(conv, bn):
+                if abs(bn.eps - 1e-5) > 1e-12:      # the packed BatchNorm fold uses the reference's eps (resnet.py: nn.BatchNorm2d default)
+                    raise NotImplementedError(f"BatchNorm eps {bn.eps}: the HIP pyramid producer folds eps = 1e-5 (set P2P_BACKBONE=miopen)")
                 return ops.ConvBN(conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.stride[0], device)
             trunk = []
             for name, _, _, _ in _STAGES:
@@ -102,11 +104,19 @@ class ResNet34(nn.Module):
                     down = pack(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
                     blocks.append((pack(blk.conv1, blk.bn1), pack(blk.conv2, blk.bn2), down))
                 trunk.append(blocks)
+            if abs(self.bn1.eps - 1e-5) > 1e-12:
+                raise NotImplementedError(f"BatchNorm eps {self.bn1.eps}: the HIP pyramid producer folds eps = 1e-5 (set P2P_BACKBONE=miopen)")
             stem = ops.Stem(self.conv1.weight, self.bn1.weight, self.bn1.bias, self.bn1.running_mean, self.bn1.running_var, device)
             self._hip_trunk_cache, self._hip_sig = (stem, trunk), sig
         return self._hip_trunk_cache
 
     def _pyramid_hip(self, x):
+        # every launch below goes to the current stream of the CURRENT device: make the input's device current (a model on
+        # cuda:1 driven from a process whose current device is cuda:0 would otherwise launch there with device-1 pointers)
+        with torch.cuda.device(x.device):
+            return self._pyramid_hip_on_current_device(x)
+
+    def _pyramid_hip_on_current_device(self, x):
         from .. import ops
         stem, trunk = self._hip_trunk(x.device)
         feats = [x]
@@ -127,7 +137,9 @@ class ResNet34(nn.Module):
 
     def pyramid(self, x):
         """[image, relu(bn1(conv1)), layer1, layer2, layer3] -- reference forward_all (resnet.py:138-157)."""
-        if x.is_cuda and not self.training and os.environ.get("P2P_BACKBONE", "hip") != "miopen":
+        # the HIP producer: fp32 inference only -- a half / double image, or one autograd has to flow through, takes the torch path
+        if (x.is_cuda and not self.training and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad)
+                and os.environ.get("P2P_BACKBONE", "hip") != "miopen"):
             return self._pyramid_hip(x)
         feats = [x]
         x = F.relu(self.bn1(self.conv1(x)), inplace=True)

@@ -134,6 +134,9 @@ def _collect_device(net, rec, ncn_thres, mutual, io_thres):
         k = int(n[b])
         if k < 0:       # a coordinate outside the device filter's packed key (an image side >= 2^15): the per-pair host path
             from .model_helper import estimate_matches
+            for f in (job[1], job[2]):      # file objects were read by the loader thread: rewind them for the second decode
+                if hasattr(f, "seek"):
+                    f.seek(0)
             out.append(estimate_matches(net, job[1], job[2], ksize=job[3], ncn_thres=ncn_thres, mutual=mutual, io_thres=io_thres,
                                         eval_type="fine", imsize=job[5]))
         else:

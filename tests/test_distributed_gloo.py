@@ -103,6 +103,48 @@ def test_bench_final_exchange_on_two_ranks():
     assert rows.shape[0] == total and len(set(ids.tolist())) <= world * steps * B
 
 
+def _weak_worker(rank, world, port, steps, B, ret):
+    """bench.py's own timed region (bench.timed_steps) and per-rank bookkeeping (bench.exchange_rank_stats) with a stand-in
+    for the matcher: what `python -m torch.distributed.run ... bench.py --gpus 2` executes, minus the GPU work."""
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+
+    def run(nsteps):
+        time.sleep(0.02 * (rank + 1))                   # ranks finish their own steps at different times
+        return [_fake_step(rank, i, B) for i in range(nsteps)]
+
+    t = bench.timed_steps(run, steps, True, rank, world, B, dev, dist)
+    roof = bench.roofline_of("fp16x2", t["events"])
+    stats = bench.exchange_rank_stats(dist, dev, world, [t["elapsed"], steps * B / t["local_elapsed"], roof["avg_launch_ms"], roof["frac"]])
+    ret[rank] = (t["nrows"], t["elapsed"], t["local_elapsed"], stats)
+    dist.destroy_process_group()
+
+
+def test_bench_weak_scaling_path_on_two_ranks():
+    """The weak-scaling leg of bench.py end to end on two gloo ranks: every rank times its own steps between the two
+    barriers, the match arrays of all ranks are gathered inside the timed region, and rank 0 receives every rank's own
+    rate and regress-launch figures (per_rank_pairs_per_s, per_rank_roofline_frac of the JSON line)."""
+    world, steps, B = 2, 3, 2
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_weak_worker, args=(world, port, steps, B, ret), nprocs=world, join=True)
+    total = sum(_fake_step(r, i, B)[0][b].shape[0] for r in range(world) for i in range(steps) for b in range(B))
+    for r in range(world):
+        nrows, elapsed, local, stats = ret[r]
+        assert nrows == total                                           # every rank holds the whole gathered set
+        assert len(stats) == world and all(len(x) == 4 for x in stats)
+        assert local <= elapsed + 1e-6
+    assert ret[0][3] == ret[1][3]                                       # the same table on every rank
+    rates = [x[1] for x in ret[0][3]]
+    assert rates[0] > rates[1] > 0                                      # rank 1 slept twice as long: its own rate is lower
+    assert max(x[0] for x in ret[0][3]) >= 0.04                         # the slowest rank's clock covers its sleep
+
+
 def _stream_worker(rank, world, port, num_pairs, chunk, gather_every, ret):
     from patch2pix_amd.gather import run_pair_stream
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))

@@ -172,3 +172,33 @@ def test_real_image_pairs_contrast_checkpoint(name, imsize):
         assert assert_decidable_rows(ref_rows, em)[0] == n_dec
     assert nd == ndiff and nd <= 16 and n_dec >= 0.4 * n
     print(f"\n{name}: {nd} of {n} rows differ between oracle and reference (fp64 gap <= {worst:.3f} of the bound); {n_dec} decidable")
+
+
+def test_local_error_model_equals_the_full_one():
+    """oracle/error_model.py: LocalErrorModel (used at 960x1280, where the full fp64 model costs minutes) evaluates the same
+    fp64 volume and the same fp32 bound as ErrorModel -- on crops around the cells asked for.  Corners, edges (where the
+    crops meet the zero padding of the convolutions) and interior cells; and the near-tie adjudication of a forced flip."""
+    from adjudicate import ErrorModel, LocalErrorModel, differing_rows_are_near_ties_local
+    from patch2pix_amd.utils import synthetic
+    sd = gu.state_dict(0)
+    p1, p2 = synthetic.make_correlated_pyramids(5, 160, 192)
+    em = ErrorModel(p1[4], p2[4], sd, 2)
+    lm = LocalErrorModel(p1[4], p2[4], sd, 2)
+    sh = tuple(em.Z.shape)
+    gen = torch.Generator().manual_seed(1)
+    cells = [(0, 0, 0, 0), (sh[0] - 1, sh[1] - 1, sh[2] - 1, sh[3] - 1), (0, sh[1] - 1, 1, 0), (1, 1, sh[2] - 1, 2)]
+    cells += [tuple(int(torch.randint(0, s, (1,), generator=gen)) for s in sh) for _ in range(6)]
+    for cell in cells:
+        z, e = lm.cell(*cell)
+        assert abs(z - float(em.Z[cell])) <= 1e-12 * max(abs(z), 1e-30) + 1e-300 and abs(e - float(em.E[cell])) <= 1e-9 * e, cell
+    # rows: the oracle's, and a copy whose first row points at the runner-up A cell of its column (a genuine difference)
+    ncn, _, _ = orc.split_params(sd)
+    corr, delta = orc.coarse_forward(p1[4], p2[4], 2, ncn)
+    rows, _ = orc.cal_coarse_matches(corr, delta, 2, 8)
+    assert differing_rows_are_near_ties_local(rows, rows, p1[4], p2[4], sd, 2) == (0, 0.0)
+    col = em.Z.reshape(sh[0] * sh[1], -1)[:, 0]
+    second = int(torch.topk(col, 2).indices[1])
+    forged = rows.clone()
+    forged[0, 0], forged[0, 1] = 8 * (2 * (second % sh[1])) + 4, 8 * (2 * (second // sh[1])) + 4
+    with pytest.raises(AssertionError):
+        differing_rows_are_near_ties_local(forged, rows, p1[4], p2[4], sd, 2)

@@ -109,6 +109,11 @@ def measure(net, H=480, W=640, pairs=4, reps=3, stream_pairs=160):
             os.environ.pop("P2P_BACKBONE", None)
         else:
             os.environ["P2P_BACKBONE"] = prev
+    try:
+        from tools import hpatches_substitute
+        out["configs2"] = hpatches_substitute.measure(net)
+    except Exception as e:      # informational
+        out["configs2_error"] = repr(e)
     out["backbone"] = ("pyramid producer = HIP convolutions of csrc/backbone.hip (fp32-equivalent fp16x2); *_miopen = the same "
                        "torch module through PyTorch-ROCm / MIOpen fp32")
     return out
