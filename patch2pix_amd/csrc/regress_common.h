@@ -36,7 +36,7 @@ struct RegressArgs {
     float *ws;                    // regress_ws_floats(n) floats of scratch (kernels with the batched FC tail; else unused)
 };
 
-// scratch of the kernels whose FC tail is batched over a work-group's proposals (regress_xn_impl.h): the pooled
+// scratch of the kernels whose FC tail is batched over a work-group's proposals (regress_h2.hip): the pooled
 // convolution features V [level][n][512] and the un-truncated mid matches [n][4] the fine level starts from
 constexpr int FC_ROWS = 16;             // proposals per FC batch = rows of a v_mfma_f32_16x16x4_f32 tile
 static inline size_t regress_ws_floats(size_t n) { return ((2 * n * 512 + 31) & ~size_t(31)) + 4 * n + 32; }

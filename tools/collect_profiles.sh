@@ -7,7 +7,7 @@
 set -u
 TAG=${1:-r02}
 shift || true
-MODES=${@:-bf16x3}
+MODES=${@:-fp16x2}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT

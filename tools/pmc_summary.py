@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Summarise rocprofv3 --pmc result databases (one per counter group) into text + the regress traffic json.
 usage: python tools/pmc_summary.py OUT_TXT OUT_JSON MODE db1 db2 ...   (or: ... MODE OUT_TXT to rebuild the json record from the text)
-OUT_JSON is keyed by regressor mode ({"bf16x3": {...}, "f32": {...}}); an existing file is updated.  Every record carries
+OUT_JSON is keyed by regressor mode ({"fp16x2": {...}, "f32": {...}}); an existing file is updated.  Every record carries
 the hash of the kernel sources it was measured with; bench.py reports `roofline.traffic` only when it matches."""
 import json
 import os

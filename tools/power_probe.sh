@@ -1,7 +1,7 @@
 #!/bin/bash
 # Sample board power and shader clock (rocm-smi) while the regress launch runs back to back.
-#   gpurun -- 'bash tools/power_probe.sh bf16x3 [lib.so]'   -> gpurun_out/power_<mode>.txt
-MODE=${1:-bf16x3}
+#   gpurun -- 'bash tools/power_probe.sh fp16x2 [lib.so]'   -> gpurun_out/power_<mode>.txt
+MODE=${1:-fp16x2}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out; mkdir -p $OUT
 [ -n "${2:-}" ] && export P2P_LIB_PATH=$2
