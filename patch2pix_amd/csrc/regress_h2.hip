@@ -160,9 +160,6 @@ __device__ __forceinline__ void splitn(const f32x4 &xa, const f32x4 &xb, float s
     }
 }
 
-#ifndef XF_STAGGER
-#define XF_STAGGER 64                   // start-slot spacing of the work-groups in units of 64 cycles (0 = all start together)
-#endif
 #ifdef XF_PIN_W                         // timing experiment (wrong results): the weight stream never advances (always cache hits)
 #define XWADV(N)
 #else
@@ -351,13 +348,6 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
     float *raw0 = (float *)(smb + XRAW0);
     float *scale = (float *)(smb + XSM_SCALE);
     float *misc = (float *)(smb + XSM_MISC);
-#if XF_STAGGER > 0
-    // De-synchronise the work-groups.  They all start together and take the same time per proposal, so their gather phases
-    // would coincide for the whole launch: 256 compute units x ~0.4 MB of 128-byte lines in one burst (the 36-byte rows of a
-    // level-1 window use a quarter of their lines) is bound by the HBM rate, while the memory idles for the rest of the period.
-    // Eight start slots XF_STAGGER x 64 cycles apart spread the bursts; a work-group keeps its offset for the whole launch.
-    for (int i = (int)((blockIdx.x >> 3) & 7); i > 0; --i) __builtin_amdgcn_s_sleep(XF_STAGGER);
-#endif
     // scratch (re-derived from the launch arguments where it is used: two more live 64-bit pointers across the convolution
     // phases spill): pooled features V [level][n][512], then the un-truncated matches of the previous level [n][4]
 #define XWS_V(lvl_) (args.ws + (size_t)(lvl_) * args.n * 512)
@@ -1008,7 +998,11 @@ int launch_regress_h2(const RegressArgs &a, int n, hipStream_t stream) {
         else cus[0] = ncu;
     }
     // persistent work-groups: one fits a compute unit (LDS), each walks its share of the proposals
+#ifdef XF_GRID_CAP                       // power experiment: only this many work-groups (= busy compute units)
+    const int ncu = std::min(cus[dev < 64 ? dev : 0], XF_GRID_CAP);
+#else
     const int ncu = cus[dev < 64 ? dev : 0];
+#endif
     P2P_REQUIRE(a.ws, P2P_EINVAL, "%s: the scratch buffer is missing", "regress_h2_kernel");
     hipLaunchKernelGGL(regress_h2_kernel, dim3(std::min(n, std::max(ncu, 1))), dim3(NT), XSM_BYTES, stream, a);
     return check_launch("regress_h2_kernel");

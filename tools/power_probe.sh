@@ -1,17 +1,20 @@
 #!/bin/bash
-# Sample board power and shader clock (rocm-smi) while the regress launch runs back to back.
-#   gpurun -- 'bash tools/power_probe.sh fp16x2 [lib.so]'   -> gpurun_out/power_<mode>.txt
-MODE=${1:-fp16x2}
+# Is the regress launch bound by the package power limit?  (run on the GPU box; needs tools/exp/lib_cap128.so, lib_cap64.so
+# from `bash tools/ab_variants.sh cap128=-DXF_GRID_CAP=128 cap64=-DXF_GRID_CAP=64`)
+#   1. the same launch on 256 / 128 / 64 compute units: with a fixed clock the time per proposal and CU would not change
+#   2. all-zero convolution weights: the same instruction stream without operand toggling in the matrix cores
+#   3. rocm-smi power / clock samples while the launch repeats
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out; mkdir -p $OUT
-[ -n "${2:-}" ] && export P2P_LIB_PATH=$2
-NPROP=6400 NITER=500 timeout 120 python $ROOT/tools/regress_bench.py $MODE > $OUT/power_${MODE}_bench.txt 2>&1 &
-PID=$!
-sleep 12
-: > $OUT/power_${MODE}.txt
-while kill -0 $PID 2>/dev/null; do
-  rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk|mclk|fclk" | tr -s ' ' | tr '\n' ';' >> $OUT/power_${MODE}.txt
-  echo >> $OUT/power_${MODE}.txt
-  sleep 0.25
-done
-tail -4 $OUT/power_${MODE}.txt; cat $OUT/power_${MODE}_bench.txt
+cd $ROOT
+export NPROP=6400 NPAIRS=16 NITER=9
+echo "== 256 CUs"; timeout 200 python tools/regress_bench.py fp16x2 2>&1 | grep median
+echo "== 128 CUs"; P2P_LIB_PATH=$ROOT/tools/exp/lib_cap128.so timeout 200 python tools/regress_bench.py fp16x2 2>&1 | grep median
+echo "== 64 CUs";  P2P_LIB_PATH=$ROOT/tools/exp/lib_cap64.so timeout 200 python tools/regress_bench.py fp16x2 2>&1 | grep median
+echo "== 256 CUs, zero weights"; ZERO_W=1 timeout 200 python tools/regress_bench.py fp16x2 2>&1 | grep median
+echo "== 256 CUs, exact f32 kernel (for the clock comparison)"; NITER=3 timeout 200 python tools/regress_bench.py f32 2>&1 | grep median
+echo "== rocm-smi while the fp16x2 launch repeats"
+(NITER=3000 timeout 100 python tools/regress_bench.py fp16x2 > /dev/null 2>&1 &)
+sleep 22
+for i in 1 2 3 4 5 6; do timeout 10 rocm-smi --showpower --showclocks 2>/dev/null | grep -i -E "power|sclk|mclk|fclk" | tr -s ' ' | tr '\n' ';'; echo; sleep 2; done
+sleep 22
+echo "== rocm-smi idle"; timeout 10 rocm-smi --showpower --showclocks --showmaxpower 2>/dev/null | grep -i -E "power|sclk" | tr -s ' '
