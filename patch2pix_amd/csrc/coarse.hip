@@ -44,10 +44,29 @@ constexpr int PREP_P = 16;    // positions per work-group (300 groups at 60x80: 
 // Writes the normalised features x 2^12 as two fp16 planes [plane][pos'][C] (|v| <= 1, so both planes stay in the normal
 // range of fp16 and v * 2^12 = p0 + p1 to within 2^-24 |v * 2^12|).  The plane stride is hw * C elements.
 constexpr float CORR_FP16_SCALE = 4096.0f;
-__global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ F, unsigned short *__restrict__ Fn, int C, int h,
-                                                   int w, int k, size_t sF, size_t sFn) {
-    F += blockIdx.z * sF;
-    Fn += blockIdx.z * sFn;
+// One launch for both images of every pair (blockIdx.y = image); the same launch resets the maxima keys of the mutual
+// matchings (nkeys words = -inf, then one word = 0: the float bits of max |X|, see mm_apply_kernel).
+struct PrepArgs {
+    const float *F[2];
+    unsigned short *Fn[2];
+    int h[2], w[2];
+    size_t sF[2];
+    int C, k;
+    size_t sFn;
+    int *keys;
+    int nkeys;
+    size_t sKeys;
+};
+__global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
+    const int img = blockIdx.y;
+    if (img == 0) {
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i <= a.nkeys) a.keys[blockIdx.z * a.sKeys + i] = (i < a.nkeys) ? KEY_NEG_INF : 0;
+    }
+    const int h = a.h[img], w = a.w[img], C = a.C, k = a.k;
+    if ((int)blockIdx.x * PREP_P >= h * w) return;
+    const float *__restrict__ F = a.F[img] + blockIdx.z * a.sF[img];
+    unsigned short *__restrict__ Fn = a.Fn[img] + blockIdx.z * a.sFn;
     __shared__ float tile[256 * (PREP_P + 1)];   // [C <= 256][17]
     __shared__ float part[16][PREP_P];
     __shared__ float inv[PREP_P];
@@ -267,40 +286,32 @@ __global__ __launch_bounds__(256) void corr_pool_kernel(const unsigned short *__
 // ------------------------------------------------------------------------------------------------
 // 3. row / column maxima of an [nA][nB] matrix (the two torch.max of ncn/model.py:165-166)
 // ------------------------------------------------------------------------------------------------
-// n keys = -inf, followed by one word = 0 (float bits of max |X| after the first mutual matching, see mm_apply_kernel)
-__global__ void fill_keys_kernel(int *p, int n, size_t sKeys) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i <= n) p[blockIdx.z * sKeys + i] = (i < n) ? KEY_NEG_INF : 0;
-}
-
-// column maxima: a thread owns one column over a 64-row chunk; chunks meet in an (order independent) atomicMax
+// One launch for both: the first gridDim.x - ceil(nA / 4) work-groups take the column maxima (a thread owns one column
+// over a 64-row chunk; chunks meet in an order independent atomicMax), the others the row maxima (one wave per row).
 // (X2: optional second addend of every value -- the fused consensus kernel leaves its two branches in two arrays)
-__global__ __launch_bounds__(256) void colmax_kernel(const float *__restrict__ X, int nA, int nB, int *ckey, size_t sX,
-                                                     size_t sKeys, const float *__restrict__ X2) {
-    X += blockIdx.z * sX;
-    if (X2) X2 += blockIdx.z * sX;
-    ckey += blockIdx.z * sKeys;
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= nB) return;
-    const int r0 = blockIdx.y * 64, r1 = min(r0 + 64, nA);
-    float cm = -INFINITY;
-    if (X2) {
-#pragma unroll 8
-        for (int r = r0; r < r1; ++r) cm = fmaxf(cm, X[(size_t)r * nB + col] + X2[(size_t)r * nB + col]);
-    } else {
-#pragma unroll 8
-        for (int r = r0; r < r1; ++r) cm = fmaxf(cm, X[(size_t)r * nB + col]);
-    }
-    atomicMax(&ckey[col], f2key(cm));
-}
-
-// row maxima: one wave per row
-__global__ __launch_bounds__(256) void rowmax_kernel(const float *__restrict__ X, int nA, int nB, int *rkey, size_t sX,
-                                                     size_t sKeys, const float *__restrict__ X2) {
+__global__ __launch_bounds__(256) void maxima_kernel(const float *__restrict__ X, int nA, int nB, int *rkey, int *ckey, size_t sX,
+                                                     size_t sKeys, const float *__restrict__ X2, int col_groups) {
     X += blockIdx.z * sX;
     if (X2) X2 += blockIdx.z * sX;
     rkey += blockIdx.z * sKeys;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    ckey += blockIdx.z * sKeys;
+    const int gcol = (nB + 255) / 256;
+    if ((int)blockIdx.x < col_groups) {
+        const int col = ((int)blockIdx.x % gcol) * 256 + threadIdx.x;
+        if (col >= nB) return;
+        const int r0 = ((int)blockIdx.x / gcol) * 64, r1 = min(r0 + 64, nA);
+        float cm = -INFINITY;
+        if (X2) {
+#pragma unroll 8
+            for (int r = r0; r < r1; ++r) cm = fmaxf(cm, X[(size_t)r * nB + col] + X2[(size_t)r * nB + col]);
+        } else {
+#pragma unroll 8
+            for (int r = r0; r < r1; ++r) cm = fmaxf(cm, X[(size_t)r * nB + col]);
+        }
+        atomicMax(&ckey[col], f2key(cm));
+        return;
+    }
+    const int row = ((int)blockIdx.x - col_groups) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= nA) return;
     const float *x = X + (size_t)row * nB;
     float rm = -INFINITY;
@@ -322,31 +333,65 @@ __device__ __forceinline__ float mm_value(float x, float max_over_b, float max_o
     return x * (xa * xb);
 }
 
-// (in place when out == X)
+// (in place when out == X).  VEC: a thread owns four adjacent columns of a row (one 16-byte load and store per array); the
+// scalar form is for volumes whose rows are not a multiple of four cells.  The divisions stay IEEE divisions (the values
+// must round like the reference's); the index split is one 32-bit division per thread.
+typedef int mm_i32x4 __attribute__((ext_vector_type(4)));
+template <bool VEC>
 __global__ __launch_bounds__(256) void mm_apply_kernel(const float *X, int nA, int nB, const int *__restrict__ rkey,
                                                        const int *__restrict__ ckey, float *out, size_t sX, size_t sKeys,
-                                                       size_t sOut, float *__restrict__ zero, int *amax, const float *X2) {
+                                                       size_t sOut, int *amax, const float *X2) {
     X += blockIdx.z * sX;
     if (X2) X2 += blockIdx.z * sX;
     rkey += blockIdx.z * sKeys;
     ckey += blockIdx.z * sKeys;
     out += blockIdx.z * sOut;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    float v = 0.f;
-    if (i < (size_t)nA * nB) {
-        const int r = (int)(i / nB), c = (int)(i - (size_t)r * nB);
-        v = mm_value(X2 ? X[i] + X2[i] : X[i], key2f(rkey[r]), key2f(ckey[c]));
-        out[i] = v;
-        if (zero) zero[blockIdx.z * sX + i] = 0.f;      // same index space: clears the accumulation target of the consensus layers
+    constexpr int V = VEC ? 4 : 1;
+    const unsigned per_row = (unsigned)nB / V;
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    float m = 0.f;
+    if (i < (unsigned)nA * per_row) {
+        const unsigned r = i / per_row, c = (i - r * per_row) * V;
+        const size_t at = (size_t)r * nB + c;
+        const float mb = key2f(rkey[r]);
+        if constexpr (VEC) {
+            f32x4 x = *(const f32x4 *)(X + at);
+            if (X2) {
+                const f32x4 y = *(const f32x4 *)(X2 + at);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] += y[j];
+            }
+            const mm_i32x4 ck = *(const mm_i32x4 *)(ckey + c);
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = mm_value(x[j], mb, key2f(ck[j]));
+                m = fmaxf(m, fabsf(v[j]));
+            }
+            *(f32x4 *)(out + at) = v;
+        } else {
+            const float v = mm_value(X2 ? X[at] + X2[at] : X[at], mb, key2f(ckey[c]));
+            out[at] = v;
+            m = fabsf(v);
+        }
     }
     if (amax) {                                     // largest magnitude of the volume (the fused consensus kernel scales its fp16 planes by it)
-        float m = fabsf(v);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
         // the word only grows: a (possibly stale) plain read first keeps nearly every wave off the atomic unit
         int *dst = amax + blockIdx.z * sKeys;
         if ((threadIdx.x & 63) == 0 && __float_as_int(m) > *(volatile int *)dst) atomicMax(dst, __float_as_int(m));
     }
+}
+
+static void launch_mm_apply(const float *X, int nA, int nB, const int *rkey, const int *ckey, float *out, size_t sX,
+                            size_t sKeys, size_t sOut, int *amax, const float *X2, size_t nz, hipStream_t stream) {
+    const bool vec = nB % 4 == 0 && sX % 4 == 0 && sOut % 4 == 0 && sKeys % 4 == 0 && ((uintptr_t)X & 15) == 0 &&
+                     ((uintptr_t)out & 15) == 0 && ((uintptr_t)X2 & 15) == 0 && ((uintptr_t)ckey & 15) == 0;
+    const size_t items = (size_t)nA * (nB / (vec ? 4 : 1));
+    const dim3 grid((unsigned)((items + 255) / 256), 1, (unsigned)nz);
+    if (vec) hipLaunchKernelGGL(mm_apply_kernel<true>, grid, dim3(256), 0, stream, X, nA, nB, rkey, ckey, out, sX, sKeys, sOut, amax, X2);
+    else hipLaunchKernelGGL(mm_apply_kernel<false>, grid, dim3(256), 0, stream, X, nA, nB, rkey, ckey, out, sX, sKeys, sOut, amax, X2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -575,10 +620,18 @@ extern "C" int p2p_coarse_forward_batch(const float *featA, const float *featB, 
         float *P = (float *)(base + ws.P), *Y = (float *)(base + ws.Y), *Y2 = (float *)(base + ws.Y2);
         int *rkey1 = (int *)(base + ws.keys), *ckey1 = rkey1 + nAc, *rkey2 = ckey1 + nBc, *ckey2 = rkey2 + nAc;
 
-        hipLaunchKernelGGL(prep_kernel, dim3(ceil_div(nA, PREP_P), 1, nz), dim3(256), 0, stream, fA, fnA, C, hA, wA, ksize,
-                           (size_t)C * nA, 2 * sWs);
-        hipLaunchKernelGGL(prep_kernel, dim3(ceil_div(nB, PREP_P), 1, nz), dim3(256), 0, stream, fB, fnB, C, hB, wB, ksize,
-                           (size_t)C * nB, 2 * sWs);
+        const int nkeys = 2 * (nAc + nBc);
+        int *xmax = rkey1 + nkeys;
+        {
+            PrepArgs pa;
+            pa.F[0] = fA; pa.F[1] = fB; pa.Fn[0] = fnA; pa.Fn[1] = fnB;
+            pa.h[0] = hA; pa.w[0] = wA; pa.h[1] = hB; pa.w[1] = wB;
+            pa.sF[0] = (size_t)C * nA; pa.sF[1] = (size_t)C * nB;
+            pa.C = C; pa.k = ksize; pa.sFn = 2 * sWs;
+            pa.keys = rkey1; pa.nkeys = nkeys; pa.sKeys = sWs;
+            const int gp = std::max(ceil_div(std::max(nA, nB), PREP_P), ceil_div(nkeys + 1, 256));
+            hipLaunchKernelGGL(prep_kernel, dim3(gp, 2, nz), dim3(256), 0, stream, pa);
+        }
         {
             const int gx = ceil_div(nB, CT), gy = ceil_div(nA, CT);
             const long long ntiles = (long long)gx * gy * nz;
@@ -592,24 +645,18 @@ extern "C" int p2p_coarse_forward_batch(const float *featA, const float *featB, 
                                    nel, gx, gy, (int)ntiles);
         }
 
-        const int nkeys = 2 * (nAc + nBc);
-        hipLaunchKernelGGL(fill_keys_kernel, dim3(ceil_div(nkeys + 1, 256), 1, nz), dim3(256), 0, stream, rkey1, nkeys, sWs);
-        int *xmax = rkey1 + nkeys;
-        const dim3 mgrid(ceil_div(nBc, 256), ceil_div(nAc, 64), nz);
-        hipLaunchKernelGGL(colmax_kernel, mgrid, dim3(256), 0, stream, P, nAc, nBc, ckey1, sWs, sWs, (const float *)nullptr);
-        hipLaunchKernelGGL(rowmax_kernel, dim3(ceil_div(nAc, 4), 1, nz), dim3(256), 0, stream, P, nAc, nBc, rkey1, sWs, sWs, (const float *)nullptr);
+        const int col_groups = ceil_div(nBc, 256) * ceil_div(nAc, 64);
+        const dim3 mgrid(col_groups + ceil_div(nAc, 4), 1, nz);
+        hipLaunchKernelGGL(maxima_kernel, mgrid, dim3(256), 0, stream, P, nAc, nBc, rkey1, ckey1, sWs, sWs, (const float *)nullptr, col_groups);
 
         // first mutual matching, in place on the pooled volume (+ max |X| for the consensus kernel's operand scale)
-        hipLaunchKernelGGL(mm_apply_kernel, dim3((unsigned)((nel + 255) / 256), 1, nz), dim3(256), 0, stream, P, nAc, nBc, rkey1,
-                           ckey1, P, sWs, sWs, sWs, (float *)nullptr, xmax, (const float *)nullptr);
+        launch_mm_apply(P, nAc, nBc, rkey1, ckey1, P, sWs, sWs, sWs, xmax, nullptr, nz, stream);
         {   // both consensus layers, both branches: relu(.) of the direct branch into Y, of the transposed one into Y2
             const int st = launch_nc_fused(P, Y, Y2, sWs, (int)nz, d0, d1, d2, d3, ncn->wfused, ncn->b2, xmax, sWs, ncn->tile, stream);
             if (st != P2P_OK) return st;
         }
-        hipLaunchKernelGGL(colmax_kernel, mgrid, dim3(256), 0, stream, Y, nAc, nBc, ckey2, sWs, sWs, Y2);
-        hipLaunchKernelGGL(rowmax_kernel, dim3(ceil_div(nAc, 4), 1, nz), dim3(256), 0, stream, Y, nAc, nBc, rkey2, sWs, sWs, Y2);
-        hipLaunchKernelGGL(mm_apply_kernel, dim3((unsigned)((nel + 255) / 256), 1, nz), dim3(256), 0, stream, Y, nAc, nBc, rkey2,
-                           ckey2, out, sWs, sWs, nel, (float *)nullptr, (int *)nullptr, Y2);
+        hipLaunchKernelGGL(maxima_kernel, mgrid, dim3(256), 0, stream, Y, nAc, nBc, rkey2, ckey2, sWs, sWs, Y2, col_groups);
+        launch_mm_apply(Y, nAc, nBc, rkey2, ckey2, out, sWs, sWs, nel, nullptr, Y2, nz, stream);
     }
     return check_launch("coarse_forward kernels");
 }

@@ -2,6 +2,7 @@
 step -- the gather of the (ragged) match arrays over RCCL/xGMI (gloo on CPU in the tests).
 The reference is single-device (model_helper.py:30); pairs are independent, so no collective is
 needed on the data path itself."""
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -18,15 +19,20 @@ def pack_results(results, rank, world, pairs_per_step, device=None, dtype=torch.
     round-robin over the ranks like `shard_pairs` deals pairs.  `device` / `dtype`: where and as what an EMPTY contribution
     is created (a rank without results must still enter the collective with tensors on its GPU: under RCCL a CPU tensor
     on one rank against GPU tensors on the others errors or hangs)."""
-    rows, ids = [], []
-    for i, (fine, score, coarse) in enumerate(results):
-        for b in range(pairs_per_step):
-            rows.append(torch.cat([fine[b], score[b][:, None], coarse[b].to(fine[b].dtype)], dim=1))
-            ids.append(torch.full((fine[b].shape[0],), (i * world + rank) * pairs_per_step + b, dtype=torch.int64,
-                                  device=fine[b].device))
-    if not rows:
+    if any(len(step[0]) < pairs_per_step for step in results):
+        raise ValueError(f"every step must hold {pairs_per_step} pairs")
+    fine = [f for step in results for f in step[0][:pairs_per_step]]
+    if not fine:
         return torch.zeros((0, 9), dtype=dtype, device=device), torch.zeros((0,), dtype=torch.int64, device=device)
-    return torch.cat(rows), torch.cat(ids)
+    score = [t for step in results for t in step[1][:pairs_per_step]]
+    coarse = [t for step in results for t in step[2][:pairs_per_step]]
+    # one concatenation per column group over ALL pairs of all steps (five launches however many pairs there are: a
+    # cat + full + convert per pair was 3 launches x 320 pairs at the end of a 20-step run), the ids from the host
+    rows = torch.cat([torch.cat(fine), torch.cat(score)[:, None], torch.cat(coarse).to(fine[0].dtype)], dim=1)
+    first = np.array([(i * world + rank) * pairs_per_step + b for i in range(len(results)) for b in range(pairs_per_step)],
+                     dtype=np.int64)
+    ids = torch.from_numpy(np.repeat(first, [int(f.shape[0]) for f in fine])).to(fine[0].device)
+    return rows, ids
 
 
 def gather_matches(rows, pair_ids, group=None):

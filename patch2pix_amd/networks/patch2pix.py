@@ -129,7 +129,6 @@ class Patch2Pix(nn.Module):
             self.regress_fine = self.regress_mid if self.shared else _Holder(_regressor_spec(rc.feat_dim))
         self.to(self.device)
         self._packed = None
-        self._copy_stream = None
         self._pinned = {}        # up to 4 tickets in flight per shape
         self._pin_turn = 0
         self.init_weights_(weights_dict=config.weights_dict)
@@ -256,16 +255,12 @@ class Patch2Pix(nn.Module):
 
     def coarse_async(self, feats1, feats2, ksize=2):
         """Enqueue the coarse stage of a batch and an asynchronous device-to-host copy of its
-        (small) match arrays on a side stream; returns a ticket for `fine_from_ticket`.  Lets a
+        (small) match arrays behind it; returns a ticket for `fine_from_ticket`.  Lets a
         caller enqueue the next batch's coarse stage before it filters the current one on the host,
         so that the host-side filter_coarse (reference networks/utils.py:38-72) never idles the GPU."""
         corr4d, delta4d = self.forward_coarse_match(feats1[-1], feats2[-1], ksize=ksize)
         matches_, score_ = self.cal_coarse_matches(corr4d, delta4d, ksize=ksize, upsample=self.upsample, center=True)
-        if self._copy_stream is None:
-            self._copy_stream = torch.cuda.Stream(device=self.device)
         main = torch.cuda.current_stream(self.device)
-        ready = torch.cuda.Event(blocking=True)
-        ready.record(main)
         # pinned staging buffers are recycled (allocating pinned memory synchronises with the device)
         key = (tuple(matches_.shape), self._pin_turn)
         self._pin_turn = (self._pin_turn + 1) % 4
@@ -279,15 +274,13 @@ class Patch2Pix(nn.Module):
             slot[2]["done"].synchronize()
             slot[2]["stale"] = True
         host_m, host_s = slot[0], slot[1]
-        # the tensors are produced on the main stream and read on the copy stream: keep the allocator from recycling them
-        matches_.record_stream(self._copy_stream)
-        score_.record_stream(self._copy_stream)
-        with torch.cuda.stream(self._copy_stream):
-            self._copy_stream.wait_event(ready)
-            host_m.copy_(matches_, non_blocking=True)
-            host_s.copy_(score_, non_blocking=True)
-            done = torch.cuda.Event(blocking=True)
-            done.record(self._copy_stream)
+        # The copies go to the stream that produced the arrays, in front of whatever the caller enqueues next: the
+        # regress launch is one persistent work-group per compute unit, so a copy kernel on a side stream that becomes
+        # ready when that launch has started would wait for its end (17 ms at 6400 proposals) -- and the host with it.
+        host_m.copy_(matches_, non_blocking=True)
+        host_s.copy_(score_, non_blocking=True)
+        done = torch.cuda.Event(blocking=True)
+        done.record(main)
         ticket = dict(feats1=feats1, feats2=feats2, matches=matches_, scores=score_, host=(host_m, host_s), done=done)
         slot[2] = ticket
         return ticket
