@@ -388,6 +388,8 @@ def stream_mode(args, net, cfg, mode, rank, world, dev, dist):
         while time.perf_counter() - t_spin < float(os.environ.get("P2P_BENCH_SPINUP", "1.5")):                      # clocks / allocator / page cache (see main)
             run_pair_stream(2 * B, 0, 1, B, submit, finish, exchange=False)
             torch.cuda.synchronize()
+        # the exchange once on every rank before the clock starts (packing kernels, RCCL channels: first use costs tens of ms)
+        run_pair_stream(min(args.pairs, 2 * B * world), rank, world, B, submit, finish, gather_every=1, device=dev)
         barrier()
         solo = None
         if rank == 0:                                                  # single-GPU reference: rank 0 alone, the others idle
@@ -538,7 +540,10 @@ def main():
         while time.perf_counter() - t_spin < float(os.environ.get("P2P_BENCH_SPINUP", "1.5")):
             run(2)
             torch.cuda.synchronize()
-        run(args.warmup)
+        # the W warm-up steps go through the same region as the timed ones, exchange included: the first use of the
+        # packing kernels and of the collectives (lazy code-object loads, RCCL channel set-up) costs tens of milliseconds
+        if args.warmup > 0:
+            timed(args.warmup, True)
         elapsed, events, nrows, local_elapsed = timed(args.steps, True)
     assert nrows == world * args.steps * B * PTMAX * cfg["panc"]
     # every rank's own numbers (weak scaling: each ran its own K steps): its rate up to the end of its own work, and the
