@@ -73,12 +73,23 @@ constexpr int XUB = XNPL * 1024;
 // block A0[64 px][64 K fp32 (+16 B)] (K = img*32 + tap*3 + c, 27 real per image); the fold buffers
 // T2[4 wave pairs][28 level-2 rows][64 n] and T3[8 waves][9 level-3 rows][64 n] fp32.  Then the fold table [img][17][17] of {scale, T row offset} (row/column 0 =
 // the zero padding ring of the convolution) and the per-pixel scale [2][256].
-constexpr int XST1 = 64 * 4 + 16;                                 // bytes per level-1 cell
-constexpr int XNC1 = 81;
-constexpr int YST2 = 64 * 2 + 16, YNC2 = 25, YPL2 = (YNC2 + 1) * YST2;  // level 2: cell stride, cells (+ a zero cell), plane stride
-constexpr int YST3 = 128 * 2 + 16, YNC3 = 9, YPL3 = (YNC3 + 1) * YST3;  // level 3
+//
+// Bank slots.  ds_read_b128 is served in four groups of 16 lanes (lanes {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same
+// + 32); a group is conflict-free when its lanes hit 16 different 16-byte slots of the 256-byte bank row.  All A-fragment
+// reads have "lane & 31 = tile row, lane >> 5 = K half" (16-row tiles: lane & 15, lane >> 4), and the tile rows of a group
+// are 16 different values mod 16, so every layout below makes the slot a bijection of (row mod 16):
+//   level 1: the 9 x 9 cell grid with a row pitch of 8 (mod 16) slots -> slot = 8 y + x = tile row (a plain [81] array,
+//            pitch 9, put three pairs of lanes of every group on one slot);
+//   level 2: cell stride 9 slots (odd); level 3 (16-row tiles, K quarter = lane >> 4): cell stride 2 slots (mod 16), so that
+//            rows 0-3/12-15 of K quarter q take the even and rows 4-11 of quarter q + 1 the odd slots;
+//   the dead rows of a cell tile (and, in conv2, taps outside the 8 x 8 map) read zeros from the piece of a zero area that
+//   keeps them on the slot of their virtual row -- one shared zero cell collided with a live row in half of the groups.
+constexpr int XST1 = 64 * 4 + 16;                                 // bytes per level-1 cell (17 slots)
+constexpr int XRP1 = 9 * XST1 + 240;                              // level-1 grid row: 168 slots = 8 (mod 16)
+constexpr int YST2 = 64 * 2 + 16, YNC2 = 25, YPL2 = (YNC2 + 3) * YST2;  // level 2: cell stride, cells (+ 432 B of zeros), plane stride
+constexpr int YST3 = 128 * 2 + 32, YNC3 = 9, YPL3 = (YNC3 + 2) * YST3;  // level 3: 18 slots per cell (+ 576 B of zeros)
 constexpr int XOFF1 = 0;
-constexpr int YOFF2 = XOFF1 + XNC1 * XST1;
+constexpr int YOFF2 = XOFF1 + 9 * XRP1;
 constexpr int YOFF3 = YOFF2 + XNPL * YPL2;
 constexpr int XIMG = YOFF3 + XNPL * YPL3;
 constexpr int XRAW0 = 2 * XIMG;                                   // float [2][3][256]
@@ -108,11 +119,15 @@ constexpr int XTABIMG = 17 * 17 * 8;
 constexpr int XSM_SCALE = XTAB + 2 * XTABIMG + 16;                // float [2][256]
 constexpr int XCONV1B = XSM_SCALE + 512 * 4;
 // conv2 phase.  H = BN1(conv1), [64 px][512 ch], is conv2's A operand, walked in four K-chunks of 128 input channels; a
-// chunk's planes are [plane][65 px][128 ch 16-bit (+16 B)] (row 64 = zeros = the padding ring of the convolution).
-constexpr int HST = 128 * 2 + 16, HPL = 65 * HST;                 // 272, 17680
+// chunk's planes are [plane][66 px][128 ch 16-bit (+16 B)]; rows 64-65 = zeros = the padding ring of the convolution.
+// The 272-byte row puts the 16 lanes of every ds_read_b128 service group (rows {0-3,12-15,20-27}, ... : 16 different
+// values mod 16) on 16 different 16-byte slots of the 256-byte bank row.  A lane whose tap falls outside the 8x8 map reads
+// zeros from the slot its virtual row would have had (piece (row + K half) & 15 of the zero rows): sending all of them
+// to ONE zero row put them on the slot of a lane with a real row -- 27 % of conv2's LDS cycles were such 2-way conflicts.
+constexpr int HST = 128 * 2 + 16, HPL = 66 * HST;                 // 272, 17952
 // two fp16 planes are as many bytes as fp32: ALL four chunks are written as planes by the BN1 pass (no conversion passes,
 // no work-group barriers inside conv2)
-constexpr int HCHUNK = XNPL * HPL;                                // 35360: planes of chunk c start at c * HCHUNK
+constexpr int HCHUNK = XNPL * HPL;                                // 35904: planes of chunk c start at c * HCHUNK
 constexpr int XCONV2B = 4 * HCHUNK;
 // both phases, then the FC batch of the level (fc_batch_parse) over the whole allocation
 constexpr int XSM_MISC = (XCONV1B > XCONV2B) ? XCONV1B : XCONV2B;  // [16] floats: 8-11 the proposal, 12-14 the fp16 scale reductions
@@ -455,7 +470,7 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                             const int rem = e - c * (Rr * Rr);
                             const float v = (j == 1) ? g1[img][k] : (j == 2) ? g2[img][k] : g3[img][k];
                             if (j == 1) {
-                                *(float *)(tb + XOFF1 + rem * XST1 + c * 4) = v;
+                                *(float *)(tb + XOFF1 + (rem / 9) * XRP1 + (rem % 9) * XST1 + c * 4) = v;
                             } else {
                                 // fp32 copy for the scale pass + the planes (exact: v = p0 + p1 + p2)
                                 *(float *)(smb + XSHARED + img * XTMPIMG + ((j == 2) ? rem * XTMP2ST : XTMP3 + rem * XTMP3ST) + c * 4) = v;
@@ -465,13 +480,13 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                 }
             }
         }
-        if (tidv < 2 * XNPL * (YST2 + YST3) / 16) {  // the zero cells: the dead rows 25-31 of the cell tile multiply zeros
-            const int per = (YST2 + YST3) / 16;
+        if (tidv < 2 * XNPL * (3 * YST2 + 2 * YST3) / 16) {  // the zero areas: the dead rows of the cell tiles multiply zeros
+            const int per = (3 * YST2 + 2 * YST3) / 16;
             const int im = tidv / (XNPL * per), pl = (tidv / per) % XNPL, q = tidv % per;
             float zf = 0.f;
             P2P_OPAQUE(zf);
-            unsigned char *z = smb + im * XIMG + ((q < YST2 / 16) ? YOFF2 + pl * YPL2 + YNC2 * YST2 + q * 16
-                                                                  : YOFF3 + pl * YPL3 + YNC3 * YST3 + (q - YST2 / 16) * 16);
+            unsigned char *z = smb + im * XIMG + ((q < 3 * YST2 / 16) ? YOFF2 + pl * YPL2 + YNC2 * YST2 + q * 16
+                                                                      : YOFF3 + pl * YPL3 + YNC3 * YST3 + (q - 3 * YST2 / 16) * 16);
             *(f32x4 *)z = (f32x4){zf, zf, zf, zf};
         }
         __syncthreads();
@@ -494,8 +509,9 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
             for (int j = 1; j < 4; ++j) {
                 const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
                 const int Cc = (j == 3) ? 128 : 64;
-                const int cj = patch_cell(XY0(img), py, j, I.H[img]) * Rr + patch_cell(XX0(img), px, j, I.W[img]);
-                const unsigned char *p = (j == 1) ? tb + XOFF1 + cj * XST1
+                const int cjy = patch_cell(XY0(img), py, j, I.H[img]), cjx = patch_cell(XX0(img), px, j, I.W[img]);
+                const int cj = cjy * Rr + cjx;
+                const unsigned char *p = (j == 1) ? tb + XOFF1 + cjy * XRP1 + cjx * XST1
                                                   : smb + XSHARED + img * XTMPIMG + ((j == 2) ? cj * XTMP2ST : XTMP3 + cj * XTMP3ST);
                 for (int c = 0; c < Cc; c += 4) {
                     const f32x4 v = *(const f32x4 *)(p + c * 4);
@@ -612,8 +628,8 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                         const int py = 2 * (p >> 3) + ky - 1, px = 2 * (p & 7) + kx - 1;
                         const bool ok = (py >= 0) && (px >= 0);
                         const int pyc = max(py, 0), pxc = max(px, 0);
-                        const int cj = patch_cell(XY0(img), pyc, 1, I.H[img]) * 9 + patch_cell(XX0(img), pxc, 1, I.W[img]);
-                        ab[t] = img * XIMG + XOFF1 + cj * XST1 + half * 32;
+                        ab[t] = img * XIMG + XOFF1 + patch_cell(XY0(img), pyc, 1, I.H[img]) * XRP1 +
+                                patch_cell(XX0(img), pxc, 1, I.W[img]) * XST1 + half * 32;
                         sc[t] = ok ? scale[img * 256 + pyc * 16 + pxc] : 0.f;
                     }
                     const unsigned char *a0 = smb + ab[0], *a1 = smb + ab[1];
@@ -642,7 +658,9 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                         const int by3 = clampi(XY0(img) >> 3, 0, (Hh >> 3) - 1), bx3 = clampi(XX0(img) >> 3, 0, (Ww >> 3) - 1);
                         const int c3y = clampi(min((by2 + c2y) >> 1, (Hh >> 3) - 1) - by3, 0, 2);
                         const int c3x = clampi(min((bx2 + c2x) >> 1, (Ww >> 3) - 1) - bx3, 0, 2);
-                        a2 = img * XIMG + YOFF2 + ((l31 < 25) ? c2y * 5 + c2x : YNC2) * YST2 + half * 16;
+                        // dead rows 25-31: the zero area, at the piece of the slot row l31 would have (9 slots per cell)
+                        a2 = img * XIMG + YOFF2 + ((l31 < 25) ? (c2y * 5 + c2x) * YST2 + half * 16
+                                                              : YNC2 * YST2 + ((((l31 - YNC2) * 9 + half) & 15) << 4));
                         a3 = img * XIMG + YOFF3 + ((l31 < 25) ? c3y * 3 + c3x : YNC3) * YST3 + half * 16;
                     }
                     const unsigned char *q2 = smb + a2, *q3 = smb + a3;
@@ -655,7 +673,9 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                         (void)q3;
                         // level 3 first: 4 K steps of 32 channels x 4 n-tiles of 16 columns, rows = the 9 cells
                         const int l16 = (tidv & 15), kb = (tidv >> 4) & 3;
-                        const unsigned char *q3r = smb + img * XIMG + YOFF3 + ((l16 < 9) ? l16 : YNC3) * YST3 + kb * 16;
+                        // dead rows 9-15: the zero area, at the piece of the slot row l16 would have (2 slots per cell, mod 16)
+                        const unsigned char *q3r = smb + img * XIMG + YOFF3 + ((l16 < 9) ? l16 * YST3 + kb * 16
+                                                                                         : YNC3 * YST3 + (((2 * (l16 - YNC3) + kb) & 15) << 4));
                         f32x4v u0, u1, u2, u3;
                         XLOADP(S0, q3r, YPL3)
                         XGROUP4(X16SLAB(X16HALFZ, u0, u1, S0, XLOADP(S1, q3r + 64, YPL3), B0, B1, B6, B7, 6),
@@ -726,9 +746,9 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
         // BN1 -> H.  Two planes: every wave writes the planes of its 64 channels into its chunk (wave >> 1).  Three planes:
         // chunk 0 (channels of waves 0, 1) as planes, the other chunks wait as fp32
         {
-            if (tidv < 4 * XNPL * (HST / 16)) {  // the all-zero padding row of every plane (of every chunk)
-                const int ch = tidv / (XNPL * (HST / 16)), pq = tidv - ch * (XNPL * (HST / 16));
-                const int pl = pq / (HST / 16), q = pq - pl * (HST / 16);
+            if (tidv < 4 * XNPL * (2 * HST / 16)) {  // the two all-zero padding rows of every plane (of every chunk)
+                const int ch = tidv / (XNPL * (2 * HST / 16)), pq = tidv - ch * (XNPL * (2 * HST / 16));
+                const int pl = pq / (2 * HST / 16), q = pq - pl * (2 * HST / 16);
                 float zf = 0.f;
                 P2P_OPAQUE(zf);
                 if (HCHUNK != 0 || ch == 0) *(f32x4 *)(smb + ch * HCHUNK + pl * HPL + 64 * HST + q * 16) = (f32x4){zf, zf, zf, zf};
@@ -792,15 +812,18 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
             for (int chunk = 0; chunk < 4; ++chunk) {
                 if (chunk == 0) __syncthreads();       // H is complete; the four chunks need no further hand-over
                 XT(9)
-                // A addresses of a tap: pixel rows of the two m-tiles (row 64 = zeros outside the 8x8 map)
+                // A addresses of a tap: pixel rows of the two m-tiles (outside the 8x8 map: the zero rows, at the 16-byte
+                // piece that keeps the lane on the bank slot of its virtual row)
                 auto rows = [&](int tap, const unsigned char *&p0, const unsigned char *&p1) {
                     const int ky = tap / 3, kx = tap - ky * 3;
                     const int oy = (l31 >> 3) + ky - 1, ox = (l31 & 7) + kx - 1;
                     const bool okx = (ox >= 0) && (ox < 8);
                     const bool ok0 = okx && (oy >= 0);
                     const bool ok1 = okx && (oy + 4 < 8);
-                    p0 = smb + chunk * HCHUNK + (ok0 ? oy * 8 + ox : 64) * HST + half * 16;
-                    p1 = smb + chunk * HCHUNK + (ok1 ? (oy + 4) * 8 + ox : 64) * HST + half * 16;
+                    const int vrow = oy * 8 + ox;
+                    const int zoff = 64 * HST + (((vrow + half) & 15) << 4);
+                    p0 = smb + chunk * HCHUNK + (ok0 ? vrow * HST + half * 16 : zoff);
+                    p1 = smb + chunk * HCHUNK + (ok1 ? (vrow + 32) * HST + half * 16 : zoff);
                 };
                 const unsigned char *p0, *p1;
                 rows(0, p0, p1);
