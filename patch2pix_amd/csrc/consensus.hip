@@ -59,6 +59,16 @@ struct NcFusedArgs {
     size_t xmax_stride;
 };
 
+// Slots (positions of 16 bytes) per channel half of a hidden plane: whole layer-1 tiles (their tail rows store zeros) + the
+// two zero slots around them, rounded up to a multiple of 16 slots = 256 bytes: the channel halves of a plane then sit on
+// the same LDS bank slots, and the 16 lanes of a ds_read_b128 service group in layer 2 -- rows {0-3, 12-15} of one half and
+// rows {4-11} of the other -- read 16 different slots (with 450 slots per half the halves were two slots apart: every
+// A-fragment read of layer 2 took two LDS cycles per group instead of one).
+__host__ __device__ __forceinline__ int nc_hidden_used(int tc, int P) {
+    const int n = (tc + 2) * P, r = ((n + 63) >> 6) * 64;
+    return (n > r ? n : r) + 2;
+}
+__host__ __device__ __forceinline__ int nc_hidden_slots(int tc, int P) { return (nc_hidden_used(tc, P) + 15) & ~15; }
 __host__ __device__ __forceinline__ int nc_yrow(int tc, int P) {
     int r = (tc * P + 3) & ~3;            // 16-byte rows
     while ((r & 63) != 4 && (r & 63) != 12 && (r & 63) != 20 && (r & 63) != 28 && (r & 63) != 36 && (r & 63) != 44 && (r & 63) != 52 && (r & 63) != 60) r += 4;
@@ -112,7 +122,7 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     const int a0 = g * a.ta;
     const int TA = a.ta, TB = FIXED ? 5 : a.tb, TC = FIXED ? 8 : a.tc, TD = FIXED ? 40 : a.td, P = FIXED ? 44 : a.P;
     const int XROWS = TC + 4, HROWS = TC + 2;
-    const int HN = max(HROWS * P, ((HROWS * P + 63) >> 6) * 64) + 2;      // whole layer-1 tiles fit (their tail rows store zeros)
+    const int HNU = FIXED ? nc_hidden_used(8, 44) : nc_hidden_used(TC, P), HN = FIXED ? nc_hidden_slots(8, 44) : nc_hidden_slots(TC, P);
     const int XPLANE = (9 * XROWS * P * 2 + 8 + 15) & ~15;   // bytes of one fp16 plane of the staged input (+ the window overrun of its
                                                              // last position; the hidden planes behind it need 16-byte alignment)
     const int HKH = HN * 16, HPLANE = 2 * HKH;               // hidden: [plane][channel half][position][8 x fp16]
@@ -121,8 +131,7 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     const int YROW = nc_yrow(TC, P), YSLOT = TB * YROW;
     unsigned char *Xs = sm;
     unsigned char *Hs = sm + 2 * XPLANE;
-    unsigned char *W2s = Hs + 2 * HPLANE;                    // layer-2 B fragments
-    float *Ya = (float *)(W2s + NCF_W2_BYTES);
+    float *Ya = (float *)(Hs + 2 * HPLANE);
     float *C1 = Ya + 3 * YSLOT;                              // [16] scale, [16] bias of layer 1's epilogue (16-byte aligned: YSLOT % 4 == 0)
     const size_t nB = (size_t)a.d2 * a.d3;
 
@@ -133,14 +142,23 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     for (int s = 0; s < 7; ++s)
 #pragma unroll
         for (int p = 0; p < 2; ++p) w1[s][p] = *(const nf4 *)(wb + ((s * 2 + p) * 64 + lane) * 16);
-    // (the 10 layer-2 fragments go to LDS: 40 more registers would not fit beside the prefetched input rows)
-    for (int i = tid; i < NCF_W2_BYTES / 16; i += NCF_THREADS) *(nf4 *)(W2s + i * 16) = *(const nf4 *)(wb + NCF_W1_BYTES + i * 16);
+    // ... and so do the 10 layer-2 B fragments (two waves per SIMD leave a wave 256 registers; re-reading them from LDS for
+    // every pair of m-tiles was a third of layer 2's ds_read_b128 traffic)
+    nf4 w2[5][2];
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) w2[s][p] = *(const nf4 *)(wb + NCF_W1_BYTES + ((s * 2 + p) * 64 + lane) * 16);
     // (made opaque so that their loads are waited for HERE: a wait inside the strip loop would also drain the input rows
     // prefetched for the next strip)
 #pragma unroll
     for (int s = 0; s < 7; ++s)
 #pragma unroll
         for (int p = 0; p < 2; ++p) P2P_OPAQUE_V4(w1[s][p]);
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) P2P_OPAQUE_V4(w2[s][p]);
     const float *cf = (const float *)(wb + NCF_W1_BYTES + NCF_W2_BYTES);
     // The fp16 planes are laid out for |X| <= 1 (what MutualMatching makes of non-negative correlations).  A volume with
     // larger values (negative correlations can do that) is scaled down by the power of two 2^E that brings its largest
@@ -159,7 +177,7 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     for (int i = tid; i < 3 * YSLOT; i += NCF_THREADS) Ya[i] = 0.f;
     for (int i = tid; i < 2 * 2 * 2; i += NCF_THREADS) {     // the pad slots before and after the hidden positions stay zero
         const int pl = i >> 2, kh = (i >> 1) & 1, end = i & 1;
-        *(nf4 *)(Hs + pl * HPLANE + kh * HKH + (end ? (HN - 1) * 16 : 0)) = (nf4){0.f, 0.f, 0.f, 0.f};
+        *(nf4 *)(Hs + pl * HPLANE + kh * HKH + (end ? (HNU - 1) * 16 : 0)) = (nf4){0.f, 0.f, 0.f, 0.f};
     }
 
     const int a_hi = min(a0 + TA, a.d0);                     // outputs of the tile: [a0, a_hi)
@@ -251,8 +269,8 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
         }
     };
 
-    // ---- S2 (layer 1): D[row = (parity s, channel o)][column = position q0 + 2 * (lane & 31) + s].  This lane's registers
-    // 4 G + j of an accumulator are s = G >> 1, o = 8 (G & 1) + 4 (lane >> 5) + j: four consecutive channels of ONE position.
+    // ---- S2 (layer 1): D[row <-> (parity s, channel o)][column = position q0 + 2 * (lane & 31) + s], with the rows ordered
+    // (pack_nc_fused) so that register r of this lane is channel r of the position of parity s = lane >> 5.
     const int l31 = lane & 31, kb5 = lane >> 5;
     const int nt1 = (HROWS * P + 63) >> 6;
     int s2qh[2] = {0, 0};
@@ -361,27 +379,32 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // bias, ReLU, zero outside the volume, scale, split: four consecutive channels of a position per register group
-            // -> one 8-byte store per plane
-            const nf4 sc0 = *(const nf4 *)(C1 + 4 * kb5), sc1 = *(const nf4 *)(C1 + 8 + 4 * kb5);
-            const nf4 bi0 = *(const nf4 *)(C1 + 16 + 4 * kb5), bi1 = *(const nf4 *)(C1 + 24 + 4 * kb5);
+            // bias, ReLU, zero outside the volume, scale, split: register r of a lane is channel r of its position
+            // q0 + 2 (lane & 31) + (lane >> 5) -> one 16-byte store per channel half and plane
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (wave + NCF_WAVES * u >= nt1) break;               // (wave-uniform) the clamped copy is not stored
                 const int q0 = (wave + NCF_WAVES * u) * 64;
+                const bool okq = (s2ok >> (2 * u + kb5)) & 1u;
+                unsigned char *dst = Hs + (q0 + 2 * l31 + kb5 + 1) * 16;      // + 1: position -1 is slot 0
 #pragma unroll
-                for (int G = 0; G < 4; ++G) {
-                    const int sp = G >> 1, kh = G & 1;
-                    const bool okq = (s2ok >> (2 * u + sp)) & 1u;
-                    const nf4 sc = kh ? sc1 : sc0, bi = kh ? bi1 : bi0;
-                    float h[4];
+                for (int kh = 0; kh < 2; ++kh) {
+                    const nf4 sa = *(const nf4 *)(C1 + 8 * kh), sb = *(const nf4 *)(C1 + 8 * kh + 4);
+                    const nf4 ba = *(const nf4 *)(C1 + 16 + 8 * kh), bb = *(const nf4 *)(C1 + 16 + 8 * kh + 4);
+                    float h[8];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) h[j] = okq ? fmaxf(fmaf(acc[u][4 * G + j], sc[j], bi[j]), 0.f) : 0.f;
-                    const unsigned pa = npk(h[0], h[1]), pb = npk(h[2], h[3]);
-                    const unsigned ra = npk(h[0] - npk_lo(pa), h[1] - npk_hi(pa)), rb = npk(h[2] - npk_lo(pb), h[3] - npk_hi(pb));
-                    unsigned char *dst = Hs + kh * HKH + (q0 + 2 * l31 + sp + 1) * 16 + 8 * kb5;      // + 1: position -1 is slot 0
-                    *(nf2 *)dst = (nf2){__uint_as_float(pa), __uint_as_float(pb)};
-                    *(nf2 *)(dst + HPLANE) = (nf2){__uint_as_float(ra), __uint_as_float(rb)};
+                    for (int j = 0; j < 4; ++j) {
+                        h[j] = okq ? fmaxf(fmaf(acc[u][8 * kh + j], sa[j], ba[j]), 0.f) : 0.f;
+                        h[4 + j] = okq ? fmaxf(fmaf(acc[u][8 * kh + 4 + j], sb[j], bb[j]), 0.f) : 0.f;
+                    }
+                    unsigned p0[4], p1[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        p0[j] = npk(h[2 * j], h[2 * j + 1]);
+                        p1[j] = npk(h[2 * j] - npk_lo(p0[j]), h[2 * j + 1] - npk_hi(p0[j]));
+                    }
+                    *(nf4 *)(dst + kh * HKH) = (nf4){__uint_as_float(p0[0]), __uint_as_float(p0[1]), __uint_as_float(p0[2]), __uint_as_float(p0[3])};
+                    *(nf4 *)(dst + kh * HKH + HPLANE) = (nf4){__uint_as_float(p1[0]), __uint_as_float(p1[1]), __uint_as_float(p1[2]), __uint_as_float(p1[3])};
                 }
             }
         }
@@ -399,24 +422,22 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
             for (int t = wave; t < nt2; t += 2 * NCF_WAVES) {
                 const int qa = t * 16, qb = qa + NCF_WAVES * 16;
                 const unsigned char *ha = Hs + min(qa + row16, TC * P - 1) * 16, *hb = Hs + min(qb + row16, TC * P - 1) * 16;
-                const unsigned char *wl = W2s + lane * 16;
                 nf4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
                 // the fragments of step st + 1 are read while the six MFMAs of step st issue (order pinned by sched_barrier)
-                nf4 fr[2][6];                                  // [buffer][a plane 0, a plane 1, b plane 0, b plane 1, w plane 0, w plane 1]
-                auto frags3 = [&](int st, nf4 (&d)[6]) {
+                nf4 fr[2][4];                                  // [buffer][a plane 0, a plane 1, b plane 0, b plane 1]
+                auto frags3 = [&](int st, nf4 (&d)[4]) {
                     d[0] = *(const nf4 *)(ha + s3off[st]); d[1] = *(const nf4 *)(ha + s3off[st] + HPLANE);
                     d[2] = *(const nf4 *)(hb + s3off[st]); d[3] = *(const nf4 *)(hb + s3off[st] + HPLANE);
-                    d[4] = *(const nf4 *)(wl + st * 2048); d[5] = *(const nf4 *)(wl + st * 2048 + 1024);
                 };
                 frags3(0, fr[0]);
 #pragma unroll
                 for (int st = 0; st < 5; ++st) {
-                    nf4 (&c)[6] = fr[st & 1];
+                    nf4 (&c)[4] = fr[st & 1];
                     if (st < 4) frags3(st + 1, fr[(st + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);
-                    accA = NCF_MFMA16(c[1], c[4], accA); accB = NCF_MFMA16(c[3], c[4], accB);
-                    accA = NCF_MFMA16(c[0], c[5], accA); accB = NCF_MFMA16(c[2], c[5], accB);
-                    accA = NCF_MFMA16(c[0], c[4], accA); accB = NCF_MFMA16(c[2], c[4], accB);
+                    accA = NCF_MFMA16(c[1], w2[st][0], accA); accB = NCF_MFMA16(c[3], w2[st][0], accB);
+                    accA = NCF_MFMA16(c[0], w2[st][1], accA); accB = NCF_MFMA16(c[2], w2[st][1], accB);
+                    accA = NCF_MFMA16(c[0], w2[st][0], accA); accB = NCF_MFMA16(c[2], w2[st][0], accB);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // D: row 4 kb + r = output position q + 4 kb + r, column n = plane (da, db).  Plain read-add-write: inside a
@@ -515,7 +536,9 @@ void pack_nc_fused(const float *w1, const float *b1, const float *w2, std::vecto
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 8; ++j) {
                     const int k = sl * 16 + 8 * (lane >> 5) + j, gq = k >> 2, e = k & 3;
-                    const int n = lane & 31, o = n & 15, s = n >> 4, dd = e - s;
+                    // A row n -> (parity s, channel o) such that the D registers of a lane (rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+                    // are the 16 channels r of ONE position of parity lane >> 5
+                    const int n = lane & 31, s = (n >> 2) & 1, o = (n & 3) + 4 * (n >> 3), dd = e - s;
                     float v = 0.f;
                     if (gq < 27 && dd >= 0 && dd <= 2) v = std::ldexp(W1b(o, gq / 9, (gq / 3) % 3, gq % 3, dd), t1[o]);
                     put2(base + sl * 2 * 64 * 16, lane, j, v);
@@ -540,7 +563,7 @@ void pack_nc_fused(const float *w1, const float *b1, const float *w2, std::vecto
 }
 
 size_t nc_fused_lds_bytes(int tb, int tc, int P) {
-    return (size_t)2 * ((9 * (tc + 4) * P * 2 + 8 + 15) & ~15) + (size_t)2 * 2 * (std::max((tc + 2) * P, (((tc + 2) * P + 63) >> 6) * 64) + 2) * 16 + (size_t)3 * tb * nc_yrow(tc, P) * 4 + 256 + NCF_W2_BYTES;
+    return (size_t)2 * ((9 * (tc + 4) * P * 2 + 8 + 15) & ~15) + (size_t)2 * 2 * nc_hidden_slots(tc, P) * 16 + (size_t)3 * tb * nc_yrow(tc, P) * 4 + 256;
 }
 
 // float bits of max |x| over n values per pair -> out[pair * out_stride] (zero beforehand); one atomic per wave
