@@ -2,24 +2,27 @@
 // symmetric branches) as ONE kernel on the fp16 matrix cores: the 16-channel hidden volume never leaves the compute unit.
 //
 // Work-group = one branch x one output tile [TA a][TB b][TC c][TD d] of the volume Y[a][b][c][d].  It walks the hidden
-// "strips" (a', b') that feed the tile, a' outer.  Per strip:
-//   S1  the 9 planes (da, db) of the input X (first MutualMatching applied) around the strip are staged in LDS as two fp16
-//       planes of X * 2^12 (|X| <= 1), rows c0-2 ... c0+TC+1, columns dt0-2 ... dt0+TD+1 -- in a RING over b, so that a step
-//       along b restages only the three planes (da, b' + 1); their loads are prefetched a phase ahead and stored behind
-//       layer 2 of the strip before (one barrier per layer, none for the staging);
-//   S2  layer 1 on v_mfma_f32_32x32x16_f16: the hidden positions of the strip are FLAT (q = row * P + column, pitch P), an
-//       n-tile = 32 even positions, M = 16 channels x the position's two parities, K = 27 taps (da, db, dc) x a 4-wide
-//       window along d (the 3 taps dd of both parities): the B fragment of a lane is two aligned 8-byte reads of X, the
-//       weights (A: 7 K-slabs, zero where a tap does not apply) live in registers; with the channels as ROWS a lane holds four
-//       consecutive channels of one position per register group.  bias + ReLU, zero outside the volume, hidden values as two
-//       fp16 planes [plane][8-channel half][position][8 channels] in LDS (one 8-byte store per group and plane);
+// "strips" (a', b') that feed the tile in SERPENTINE order (a' ascending; b' ascending in even rows of the GLOBAL index a',
+// descending in odd ones), so that every step brings exactly ONE new triple of input planes.  Per strip:
+//   S1  the 9 planes (da, db) of the input X (first MutualMatching applied) around the strip live in LDS as two fp16 planes
+//       of X * 2^12 (|X| <= 1), rows c0-2 ... c0+TC+1, columns dt0-2 ... dt0+TD+1, in a 2-D RING: plane (a, b) sits in slot
+//       (a mod 3, b mod 3).  The new triple of the NEXT strip is loaded into registers at the top of this strip (one set of
+//       load destinations) and converted / stored behind this strip's layer 2: two barriers per strip, none for the staging;
+//   S2  layer 1 on v_mfma_f32_32x32x16_f16 with the CHANNELS as MFMA rows: A = the 7 weight fragments (registers, zero where
+//       a tap does not apply), B = 32 even flat positions (q = row * P + column, pitch P) x K = 27 taps (da, db, dc) x a
+//       4-wide window along d (the 3 taps dd of both parities; two aligned 8-byte reads of X per lane and tap group).  The A
+//       rows are ordered so that the 16 D registers of a lane are the 16 channels of ONE position (parity = lane >> 5):
+//       bias + ReLU, zero outside the volume, split -> one 16-byte store per channel half and plane,
+//       hidden planes [plane][8-channel half][position][8 x fp16]; a channel half is a multiple of 256 bytes long, so both
+//       halves sit on the same bank slots and layer 2's fragment reads are conflict-free;
 //   S3  layer 2 on v_mfma_f32_16x16x32_f16 in "gather" form over the B taps: an m-tile = 16 flat OUTPUT positions, K = 9 taps
-//       (dc, dd) x 16 channels (every A fragment is one aligned 16-byte read of the hidden planes), N = the 9 taps (da, db):
-//       column n is this strip's contribution to the output plane (a' - da + 1, b' - db + 1), added to the tile's
-//       accumulators in LDS with ds_add_f32.  Inside a strip no two adds meet (different positions or different planes),
-//       strips are separated by barriers: the summation order of every output is fixed.
-// An output slice a is complete once hidden slice a + 1 is done: relu(sum + b2) is added to Y (zeroed beforehand; the two
-// branches are its two addends, so the result does not depend on which arrives first) and its accumulator slot recycled.
+//       (dc, dd) x 16 channels (every A fragment is one aligned 16-byte read of the hidden planes; the 10 B fragments of
+//       the weights live in registers), N = the 9 taps (da, db): column n is this strip's contribution to the output plane
+//       (a' - da + 1, b' - db + 1), added to the tile's accumulators in LDS by plain read-add-write (inside a strip no two
+//       lanes touch the same word; ds_add_f32 cost ~600 cycles per wave instruction).  Strips are separated by barriers and
+//       their order depends on the global a' only: the summation order of every output cell is fixed, whatever the tile.
+// An output slice a is complete once hidden slice a + 1 is done: relu(sum + b2) is written out (the two branches into two
+// arrays, or added into one that was zeroed beforehand) at the top of the next strip and its accumulator slot recycled.
 //
 // Arithmetic: fp32-equivalent like the other 16-bit paths -- operands scaled by exact powers of two into the normal range of
 // fp16 and split into two planes (2^-24 relative), three MFMA products per fp32 product, fp32 accumulation; the scales

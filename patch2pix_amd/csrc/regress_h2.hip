@@ -67,8 +67,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int XUB = XNPL * 1024;
 
 // ---- LDS layout (bytes) --------------------------------------------------------------------------
-// conv1 phase, per image: level 1 as fp32 [81 cells][64 ch (+16 B pad)]; levels 2 and 3 as two fp16 planes
-// [plane][25 cells + a zero cell][64 ch (+16 B)] and [plane][9 cells + a zero cell][128 ch (+16 B)].  Then level 0 raw [img][3][256] and one
+// conv1 phase, per image: level 1 as fp32 [9 grid rows (+240 B)][9 cells][64 ch (+16 B pad)]; levels 2 and 3 as two fp16 planes
+// [plane][25 cells + 432 B of zeros][64 ch (+16 B)] and [plane][9 cells + 576 B of zeros][128 ch (+32 B)] ("Bank slots" below).
+// Then level 0 raw [img][3][256] and one
 // shared region that is, in turn: the fp32 copy of levels 2/3 the scale pass reads; the pre-scaled level-0 im2col
 // block A0[64 px][64 K fp32 (+16 B)] (K = img*32 + tap*3 + c, 27 real per image); the fold buffers
 // T2[4 wave pairs][28 level-2 rows][64 n] and T3[8 waves][9 level-3 rows][64 n] fp32.  Then the fold table [img][17][17] of {scale, T row offset} (row/column 0 =
