@@ -83,9 +83,9 @@ void p2p_regressor_destroy(p2p_regressor *reg);
  *   P2P_REGRESS_F32    v_mfma_f32_32x32x2_f32, bit-identical to an fp32 fma chain;
  *   P2P_REGRESS_BF16X2 reduced precision, opt-in only: two bf16 per operand (16 significant bits), three
  *                      products; regressed coordinates within ~2.5e-4 px of an fp64 evaluation.
- * New handles start in the mode named by the environment variable P2P_REGRESS_MODE ("f32" | "fp16x2" | "bf16x2", read
- * when the handle is created), else P2P_REGRESS_DEFAULT.  Only the weight stream of the mode in use is packed and
- * uploaded; p2p_regressor_set_mode builds another mode's on its first selection (host-side packing + one upload).   */
+ * New handles start in P2P_REGRESS_DEFAULT (the library reads no environment variables; the Python host layer maps
+ * P2P_REGRESS_MODE onto p2p_regressor_set_mode).  Only the weight stream of the mode in use is packed and uploaded;
+ * p2p_regressor_set_mode builds another mode's on its first selection (host-side packing + one upload).   */
 #define P2P_REGRESS_F32     0
 #define P2P_REGRESS_BF16X2  1
 #define P2P_REGRESS_FP16X2  3
@@ -237,6 +237,10 @@ int p2p_regress_batch_dev(const p2p_regressor *reg1, const p2p_regressor *reg2, 
 typedef struct p2p_conv p2p_conv;
 int p2p_conv_create(const float *weight, const p2p_bn_params *bn, int ci, int co, int ks, int stride, p2p_conv **out);
 void p2p_conv_destroy(p2p_conv *conv);
+/* Experiments / tests: force the work-group tile (mt, nt, wn) of this layer's launches -- [32 mt (4 / wn) pixels] x
+ * [32 nt wn channels]; (0,0,0) = chosen from the launch size (default).  A tile the layer does not have is ignored.  The
+ * result does not depend on the tile (every tile sums an output's K axis in the same order).                          */
+int p2p_conv_set_tile(p2p_conv *conv, int mt, int nt, int wn);
 
 /* y = [relu](bn(conv(x)) [+ residual]) for a batch of n images.  Activations are fp32 **NHWC** device arrays
  * (x [n,h,w,ci], y and residual [n,ho,wo,co], ho = (h + 2 (ks/2) - ks) / stride + 1); xmax [n] holds the float bits of

@@ -426,8 +426,8 @@ static int conv_nit(const ConvCfg &c, int ks, int stride) {
 // slabs of weights in flight, 152 registers = three work-groups per compute unit) wins up to ~500 tiles and for every 1x1
 // and stride-2 layer; from there the 128 x 128 tile, and the 128 x 256 tile (24 MFMAs per 4 fragment reads and 8 weight
 // loads, but two work-groups per compute unit and one slab in flight) only for launches of several rounds.
-// P2P_CONV_TILE="mt,nt,wn" forces one (experiments).
-static ConvCfg conv_cfg(int co, int ks, int stride, long tiles128) {
+// p2p_conv_set_tile forces one per handle (experiments, the tile-independence tests).
+static ConvCfg conv_cfg(int co, int ks, int stride, long tiles128, const int *forced) {
     static const ConvCfg cand256[] = {{2, 4, 2, 0}, {1, 4, 2, 0}, {2, 2, 2, 0}, {1, 2, 2, 0}};
     static const ConvCfg cand128[] = {{2, 2, 2, 0}, {1, 2, 2, 0}};
     static const ConvCfg cand64[] = {{1, 2, 1, 0}};
@@ -438,12 +438,9 @@ static ConvCfg conv_cfg(int co, int ks, int stride, long tiles128) {
         if (co % 256 == 0 && tiles128 >= 512) best = tiles128 >= 1024 ? cand256[0] : cand256[2];
         if (co % 256 != 0 && co % 128 == 0 && tiles128 >= 1024) best = cand128[0];
     }
-    if (const char *e = getenv("P2P_CONV_TILE")) {
-        int mt = 0, nt = 0, wn = 0;
-        if (sscanf(e, "%d,%d,%d", &mt, &nt, &wn) == 3)
-            for (int i = 0; i < ncand; ++i)
-                if (cand[i].mt == mt && cand[i].nt == nt && cand[i].wn == wn) best = cand[i];
-    }
+    if (forced && forced[0] > 0)         // (a tile the layer does not have is ignored)
+        for (int i = 0; i < ncand; ++i)
+            if (cand[i].mt == forced[0] && cand[i].nt == forced[1] && cand[i].wn == forced[2]) best = cand[i];
     best.nit = conv_nit(best, ks, stride);
     return best;
 }
@@ -454,9 +451,16 @@ struct p2p_conv {
     unsigned char *wq;
     float *sc, *sh;          // one allocation behind wq
     int ci, co, ks, stride;
+    int tile[3];             // forced (mt, nt, wn); 0 = by the launch size
 };
 
 using namespace p2p;
+
+extern "C" int p2p_conv_set_tile(p2p_conv *cv, int mt, int nt, int wn) {
+    P2P_REQUIRE(cv && mt >= 0 && nt >= 0 && wn >= 0, P2P_EINVAL, "p2p_conv_set_tile: bad argument");
+    cv->tile[0] = mt; cv->tile[1] = nt; cv->tile[2] = wn;
+    return P2P_OK;
+}
 
 extern "C" int p2p_conv_create(const float *weight, const p2p_bn_params *bn, int ci, int co, int ks, int stride, p2p_conv **out) {
     P2P_REQUIRE(weight && bn && out, P2P_EINVAL, "p2p_conv_create: null argument");
@@ -541,7 +545,7 @@ extern "C" int p2p_conv_forward(const p2p_conv *cv, const float *x, const int *x
     P2P_REQUIRE(n >= 1 && h >= 1 && w >= 1, P2P_EINVAL, "p2p_conv_forward: bad extents %d x %d x %d", n, h, w);
     const int pad = cv->ks / 2;
     const int ho = (h + 2 * pad - cv->ks) / cv->stride + 1, wo = (w + 2 * pad - cv->ks) / cv->stride + 1;
-    const ConvCfg c = conv_cfg(cv->co, cv->ks, cv->stride, (long)n * ceil_div(ho, 8) * ceil_div(wo, 16));
+    const ConvCfg c = conv_cfg(cv->co, cv->ks, cv->stride, (long)n * ceil_div(ho, 8) * ceil_div(wo, 16), cv->tile);
     ConvArgs a{};
     a.x = x; a.res = residual; a.y = y; a.xmax = xmax; a.ymax = ymax; a.wq = cv->wq; a.sc = cv->sc; a.sh = cv->sh;
     a.n = n; a.h = h; a.w = w; a.ci = cv->ci; a.co = cv->co; a.ks = cv->ks; a.stride = cv->stride; a.relu = relu; a.ck = conv_ck(cv->stride);

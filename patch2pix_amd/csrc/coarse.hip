@@ -132,7 +132,9 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
 // "block-major" order: blocks of CX_AB tile rows (their A panels, CX_AB x 128 KB, stay in the L2), inside a block column
 // after column of B tiles -- each B panel is fetched once per block instead of once per tile row.
 constexpr int CT = 128;      // tile edge
-constexpr int CX_AB = 16;    // tile rows per L2-resident block of A panels (16 x 128 KB = 2 MB of the 4 MB L2)
+constexpr int CX_AB = 16;    // tile rows per L2-resident block of A panels (16 x 128 KB = 2 MB of the 4 MB L2; measured at
+                             // 960x1280: 16 rows fetch 224 MB per pair, 24 rows 246 MB, 28 rows 682 MB -- the streaming B
+                             // panels and the output need the other half)
 typedef _Float16 cf16x8 __attribute__((ext_vector_type(8)));
 constexpr int CX_ROW = 32 * 2 + 16;          // bytes per LDS row: 80 = 5 x 16 (odd multiple of 16 B: the 16 lanes of every ds_read_b128
                                              // service group -- rows {0-3,12-15,20-27} etc. -- land on 16 different 16-byte slots)

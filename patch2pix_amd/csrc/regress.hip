@@ -344,17 +344,9 @@ static void fold_bn(const p2p_bn_params &bn, int n, float *scale, float *shift) 
 
 using namespace p2p;
 
-// Arithmetic of the two convolutions: the environment variable P2P_REGRESS_MODE ("f32" | "fp16x2" | "bf16x2") picks the
-// mode newly created regressors start in (read at creation, nothing is cached); p2p_regressor_set_mode overrides it per
-// handle.  Only the weight stream of the mode in use is packed and uploaded; another mode's is built on its first selection.
-static int default_regress_mode() {
-    const char *e = std::getenv("P2P_REGRESS_MODE");
-    if (e && std::strcmp(e, "f32") == 0) return P2P_REGRESS_F32;
-    if (e && std::strcmp(e, "bf16x2") == 0) return P2P_REGRESS_BF16X2;
-    if (e && std::strcmp(e, "fp16x2") == 0) return P2P_REGRESS_FP16X2;
-    return P2P_REGRESS_DEFAULT;
-}
-
+// Arithmetic of the two convolutions: new regressors start in P2P_REGRESS_DEFAULT, p2p_regressor_set_mode selects another
+// mode per handle (the library reads no environment variables).  Only the weight stream of the mode in use is packed and
+// uploaded; another mode's is built on its first selection.
 static int upload(const std::vector<float> &h, float **dev, const char *what) {
     *dev = nullptr;
     P2P_HIP_CHECK(hipMalloc(dev, h.size() * sizeof(float)));
@@ -492,7 +484,7 @@ extern "C" int p2p_regressor_create(const p2p_regressor_params *p, p2p_regressor
     r->fc2t = dev + o_fc2t; r->fc2b = dev + o_fc2b; r->bnf2s = dev + o_bnf2s; r->bnf2b = dev + o_bnf2b;
     r->fc3 = dev + o_fc3; r->fc3b = dev + o_fc3b;
     r->fc1p = dev + o_fc1p; r->fc2p = dev + o_fc2p;
-    r->mode = default_regress_mode();
+    r->mode = P2P_REGRESS_DEFAULT;
     st = ensure_mode(r, r->mode);
     if (st != P2P_OK) {
         p2p_regressor_destroy(r);

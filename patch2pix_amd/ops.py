@@ -2,6 +2,7 @@
 Every function launches asynchronously on torch's current HIP stream of the tensors' device."""
 import ctypes
 import math
+import os
 
 import torch
 
@@ -44,6 +45,11 @@ class NcnWeights:
             self.handle = None
 
 
+# Experiments and the tile-independence tests: (mt, nt, wn) forced on every ConvBN launch (p2p_conv_set_tile); None = the
+# library picks by launch size.  The environment variable P2P_CONV_TILE="mt,nt,wn" sets it at import (tools).
+FORCED_CONV_TILE = tuple(int(v) for v in os.environ["P2P_CONV_TILE"].split(",")) if os.environ.get("P2P_CONV_TILE") else None
+
+
 class ConvBN:
     """Device-resident packed Conv2d(bias=False) + BatchNorm2d (eval) of the pyramid producer
     (reference networks/resnet.py:26-60); `forward` works on fp32 NHWC activations."""
@@ -60,6 +66,7 @@ class ConvBN:
                        "p2p_conv_create")
         self.ci, self.co, self.ks, self.stride = ci, co, ks, int(stride)
         self.device = torch.device(device)
+        self._tile = None
 
     def __del__(self):
         if getattr(self, "handle", None) and _lib is not None:
@@ -72,6 +79,9 @@ class ConvBN:
         n, h, w, ci = x.shape
         if ci != self.ci or x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous():
             raise TypeError(f"ConvBN.forward: expected a contiguous float32 NHWC tensor with {self.ci} channels on the GPU")
+        if FORCED_CONV_TILE != self._tile:
+            _lib.check(_lib.p2p_conv_set_tile(self.handle, *(FORCED_CONV_TILE or (0, 0, 0))), "p2p_conv_set_tile")
+            self._tile = FORCED_CONV_TILE
         pad = self.ks // 2
         ho, wo = (h + 2 * pad - self.ks) // self.stride + 1, (w + 2 * pad - self.ks) // self.stride + 1
         y = torch.empty((n, ho, wo, self.co), device=x.device, dtype=torch.float32)
@@ -167,11 +177,16 @@ class RegressorWeights:
         with torch.cuda.device(device):
             _lib.check(_lib.p2p_regressor_create(ctypes.byref(p), ctypes.byref(self.handle)), "p2p_regressor_create")
         self.device = torch.device(device)
+        env = os.environ.get("P2P_REGRESS_MODE")       # tools: the mode new handles start in (read here, not in the library)
+        if env:
+            self.set_mode(env)
 
     def set_mode(self, mode):
         """'fp16x2' (default: fp32-equivalent, two fp16 planes under exact power-of-two scales, 3 MFMA products), 'f32'
         (exact fp32 MFMA) or 'bf16x2' (reduced precision, 16 significant bits; opt-in).  The first selection of a
         non-default mode packs and uploads that mode's weight stream (host work, ~1 s)."""
+        if mode not in _lib.REGRESS_MODES:
+            raise ValueError(f"unknown regressor mode {mode!r}: one of {sorted(_lib.REGRESS_MODES)}")
         _lib.check(_lib.p2p_regressor_set_mode(self.handle, _lib.REGRESS_MODES[mode]), "p2p_regressor_set_mode")
 
     @property

@@ -170,7 +170,7 @@ def _bn(bn):
     return real.BnParams(*[t.data_ptr() for t in bn])
 
 
-def conv_bn(emu, weight, bn, stride, x_nchw, residual_nchw=None, relu=True):
+def conv_bn(emu, weight, bn, stride, x_nchw, residual_nchw=None, relu=True, tile=None):
     """p2p_conv_create + p2p_absmax_batch + p2p_conv_forward on CPU tensors (NCHW in and out; the kernel works on NHWC).
     -> (y [n,co,ho,wo], float max |y| per image as the kernel reports it)."""
     co, ci, ks, _ = weight.shape
@@ -178,6 +178,8 @@ def conv_bn(emu, weight, bn, stride, x_nchw, residual_nchw=None, relu=True):
     b = _bn(keep[1:])
     h = ctypes.c_void_p()
     check(emu, emu.p2p_conv_create(ptr(keep[0]), ctypes.byref(b), ci, co, ks, stride, ctypes.byref(h)), "p2p_conv_create")
+    if tile:
+        check(emu, emu.p2p_conv_set_tile(h, *tile), "p2p_conv_set_tile")
     n, _, hh, ww = x_nchw.shape
     x = x_nchw.permute(0, 2, 3, 1).contiguous()
     xmax = torch.zeros(n, dtype=torch.int32)

@@ -1232,6 +1232,7 @@ def test_backbone_pyramid_vs_fp64(hw, dev, monkeypatch, capsys):
 def test_backbone_batch_and_tile_independence(dev, monkeypatch):
     """An image's pyramid does not depend on its batch mates (operand scales are per image) nor on the tile the launch
     heuristic picks (every tile sums an output's K axis in the same order): bit-identical."""
+    from patch2pix_amd import ops
     net = _extract(dev).to(dev)
     x = _image_batch([5, 6, 7], 120, 168).to(dev)
     x[1] *= 40.0                                                     # a batch mate on a very different scale
@@ -1242,8 +1243,8 @@ def test_backbone_batch_and_tile_independence(dev, monkeypatch):
             one = net.pyramid(x[i:i + 1].contiguous())
             for lv in range(1, 5):
                 assert torch.equal(one[lv][0], full[lv][i]), f"image {i} level {lv}"
-        for tile in ("2,4,2", "1,4,2", "2,2,2", "1,2,2"):
-            monkeypatch.setenv("P2P_CONV_TILE", tile)
+        for tile in ((2, 4, 2), (1, 4, 2), (2, 2, 2), (1, 2, 2)):
+            monkeypatch.setattr(ops, "FORCED_CONV_TILE", tile)
             other = net.pyramid(x)
             for lv in range(1, 5):
                 assert torch.equal(other[lv], full[lv]), f"tile {tile} level {lv}"

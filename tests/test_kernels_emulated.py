@@ -431,9 +431,7 @@ def _bn_eval64(t, bn):
     (256, 256, 3, 1, 1, 5, 16, True, True, "1,4,2"),
     (256, 256, 3, 1, 1, 10, 16, True, True, "2,2,2"),
 ])
-def test_backbone_convolution_against_torch(ci, co, ks, stride, n, h, w, res, relu, tile, emu, monkeypatch):
-    if tile:
-        monkeypatch.setenv("P2P_CONV_TILE", tile)
+def test_backbone_convolution_against_torch(ci, co, ks, stride, n, h, w, res, relu, tile, emu):
     gen = torch.Generator().manual_seed(ci * 7 + co + ks + stride)
     wt = torch.randn(co, ci, ks, ks, generator=gen) * (2.0 / (ci * ks * ks)) ** 0.5
     bn = _bn_params(co, gen)
@@ -444,7 +442,7 @@ def test_backbone_convolution_against_torch(ci, co, ks, stride, n, h, w, res, re
         ref = ref + skip.double()
     if relu:
         ref = ref.relu()
-    got, gmax = emu_lib.conv_bn(emu, wt, bn, stride, x, skip, relu)
+    got, gmax = emu_lib.conv_bn(emu, wt, bn, stride, x, skip, relu, tile=tuple(int(v) for v in tile.split(",")) if tile else None)
     assert got.shape == ref.shape
     scale = ref.abs().amax(dim=(1, 2, 3), keepdim=True)
     assert ((got.double() - ref).abs() / scale).max().item() < BACKBONE_TOL

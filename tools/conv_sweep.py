@@ -1,4 +1,4 @@
-"""Time every tile variant of the backbone convolution (P2P_CONV_TILE) per layer shape and batch size."""
+"""Time every tile variant of the backbone convolution (ops.FORCED_CONV_TILE -> p2p_conv_set_tile) per layer shape and batch size."""
 import os
 import sys
 import time
@@ -35,10 +35,7 @@ for ci, co, ks, st, h, w in ((64, 64, 3, 1, H // 4, W // 4), (64, 128, 3, 2, H /
         fl = 2.0 * nb * (h // st) * (w // st) * co * ci * ks * ks
         res = []
         for t in tiles + ["auto"]:
-            if t == "auto":
-                os.environ.pop("P2P_CONV_TILE", None)
-            else:
-                os.environ["P2P_CONV_TILE"] = t
+            ops.FORCED_CONV_TILE = None if t == "auto" else tuple(int(v) for v in t.split(","))
             ms = timed(lambda: cv.forward(x, xm))
             res.append(f"{t}: {ms:.3f} ms ({fl / ms / 1e9:.0f} TF)")
         print(f"conv {ci:3d}->{co:3d} k{ks} s{st} {h}x{w} x{nb:2d}:  " + "   ".join(res), flush=True)
