@@ -135,7 +135,6 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     unsigned char *Xs = sm;
     unsigned char *Hs = sm + 2 * XPLANE;
     float *Ya = (float *)(Hs + 2 * HPLANE);
-    float *C1 = Ya + 3 * YSLOT;                              // [16] scale, [16] bias of layer 1's epilogue (16-byte aligned: YSLOT % 4 == 0)
     const size_t nB = (size_t)a.d2 * a.d3;
 
     // weights of this branch -> registers (layer 1: the A operands of its MFMAs)
@@ -171,10 +170,13 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     const float up = __int_as_float((127 + E) << 23), down = __int_as_float((127 - E) << 23);
     const float xscale = 4096.0f * down;
     const float yun = cf[33] * up;
-    if (tid < 16) {      // relu(acc * s1 + b1) * hscale = relu(acc * (s1 hscale) + b1 hscale): layer 1's epilogue constants per channel
+    // relu(acc * s1 + b1) * hscale = relu(acc * (s1 hscale) + b1 hscale): layer 1's epilogue constants per channel, in
+    // registers for the whole kernel (they were re-read from LDS for every tile of every strip)
+    float e1s[16], e1b[16];
+    {
         const float hscale = cf[32] * down;
-        C1[tid] = cf[tid] * up * hscale;
-        C1[16 + tid] = cf[16 + tid] * hscale;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { e1s[c] = cf[c] * up * hscale; e1b[c] = cf[16 + c] * hscale; }
     }
 
     for (int i = tid; i < 3 * YSLOT; i += NCF_THREADS) Ya[i] = 0.f;
@@ -211,44 +213,58 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     // ---- S1: this lane's pair of columns of a staged row (strip-independent)
     const int nbp = bp_last - bp_first + 1, nstrips = (ap_last - ap_first + 1) * nbp;
     const int sB = (int)nB, sA = a.d1 * sB;                  // 32-bit element offsets (a volume has < 2^31 cells)
-    const int cp = lane & 31, rh = lane >> 5;
+    // Lanes and items beyond the layout (column pairs >= P / 2, rows >= XROWS, items 18 and 19) are made exact DUPLICATES of the
+    // last valid column pair / row: same source, same destination, same value -- so the staging needs no validity branches.
+    const int cp = min(lane & 31, P / 2 - 1), rh = lane >> 5;
     const int dcol = dt0 - 2 + 2 * cp;
     const int coff0 = clampi(dcol, 0, a.d3 - 1), coff1 = clampi(dcol + 1, 0, a.d3 - 1);
-    const bool okd0 = 2 * cp < P && dcol >= 0 && dcol < a.d3, okd1 = 2 * cp < P && dcol + 1 >= 0 && dcol + 1 < a.d3;
+    const bool okd0 = dcol >= 0 && dcol < a.d3, okd1 = dcol + 1 >= 0 && dcol + 1 < a.d3;
     // item k of this wave = (plane da of the triple (., db), row pair rp); loads are unconditional from clamped addresses, the
-    // zero padding is selected when the value is USED (a load in a branch, or a select right behind it, is waited for on
+    // zero padding is applied when the value is USED (a load in a branch, or a select right behind it, is waited for on
     // the spot).  q0v / q1v are the ONLY load destinations inside the strip loop (a second set -- e.g. for the nine planes
     // of a row start -- makes the compiler wait for every outstanding load, the prefetched ones included, before the first
     // MFMA of a strip).
     float q0v[NCF_KRING], q1v[NCF_KRING];
     // strip-independent parts of this lane's items: source row offset (clamped c row), byte offset of the row pair inside an
-    // LDS plane, validity bits (bit k: the lane stores something for item k; bit 8 + k: its row is inside the volume)
+    // LDS plane, and the factor of each of its two values: 2^12 / 2^E inside the volume, 0 in the zero padding
     int crow[NCF_KRING], lrow[NCF_KRING];
-    unsigned okbits = 0;
+    float m0v[NCF_KRING], m1v[NCF_KRING];
 #pragma unroll
     for (int k = 0; k < NCF_KRING; ++k) {
-        const int it = wave + NCF_WAVES * k, i3 = it / 6, rp = it - 6 * i3;
-        const int xr = 2 * rp + rh, ic = c0 - 2 + xr;
+        const int it = wave + NCF_WAVES * k, i3 = min(it / 6, 2), rp = it - 6 * i3;
+        const int xr = min(2 * rp + rh, XROWS - 1), ic = c0 - 2 + xr;
         crow[k] = clampi(ic, 0, a.d2 - 1) * a.d3;
         lrow[k] = (xr * P + 2 * cp) * 2;
-        okbits |= (unsigned)(i3 < 3 && xr < XROWS && 2 * cp < P) << k;
-        okbits |= (unsigned)(ic >= 0 && ic < a.d2) << (8 + k);
+        const bool rowok = ic >= 0 && ic < a.d2;
+        m0v[k] = (rowok && okd0) ? xscale : 0.f;
+        m1v[k] = (rowok && okd1) ? xscale : 0.f;
     }
     // a triple = the three planes (pa + i, pb) (along a) or (pa, pb + i) (along b); plane (ia, ib) sits in slot (ia mod 3,
     // ib mod 3) of the 2-D ring.  Per item (scalars, once per strip): clamped source offset of its plane, inside the volume?,
     // byte offset of the plane's slot.
     int isrc[NCF_KRING], idst[NCF_KRING];
     bool iin[NCF_KRING];
+    // (three plane descriptors per strip; item k of wave w belongs to plane min((w + 4 k) / 6, 2): 0, w >= 2, 1, 2, 2)
+    const bool k1_second = wave >= 2;
     auto triple = [&](int pa, int pb, bool along_a) {
+        int src3[3], dst3[3];
+        bool in3[3];
+        const int ma = (pa + 3) % 3, mb = (pb + 3) % 3;          // ring slot of the first plane; the others follow cyclically
 #pragma unroll
-        for (int k = 0; k < NCF_KRING; ++k) {
-            const int i3 = min((wave + NCF_WAVES * k) / 6, 2);
-            const int ia = along_a ? pa + i3 : pa, ib = along_a ? pb : pb + i3;
-            isrc[k] = clampi(ia, 0, a.d0 - 1) * sA + clampi(ib, 0, a.d1 - 1) * sB;
-            iin[k] = ia >= 0 && ia < a.d0 && ib >= 0 && ib < a.d1;
-            idst[k] = (((ia + 3) % 3) * 3 + (ib + 3) % 3) * XROWS * P * 2;
+        for (int i = 0; i < 3; ++i) {
+            const int ia = along_a ? pa + i : pa, ib = along_a ? pb : pb + i;
+            const int sa = along_a ? (ma + i >= 3 ? ma + i - 3 : ma + i) : ma, sb = along_a ? mb : (mb + i >= 3 ? mb + i - 3 : mb + i);
+            src3[i] = clampi(ia, 0, a.d0 - 1) * sA + clampi(ib, 0, a.d1 - 1) * sB;
+            in3[i] = ia >= 0 && ia < a.d0 && ib >= 0 && ib < a.d1;
+            dst3[i] = (sa * 3 + sb) * XROWS * P * 2;
         }
+        isrc[0] = src3[0]; iin[0] = in3[0]; idst[0] = dst3[0];
+        isrc[1] = k1_second ? src3[1] : src3[0]; iin[1] = k1_second ? in3[1] : in3[0]; idst[1] = k1_second ? dst3[1] : dst3[0];
+        isrc[2] = src3[1]; iin[2] = in3[1]; idst[2] = dst3[1];
+        isrc[3] = src3[2]; iin[3] = in3[2]; idst[3] = dst3[2];
+        isrc[4] = src3[2]; iin[4] = in3[2]; idst[4] = dst3[2];
     };
+    static_assert(NCF_KRING == 5 && NCF_WAVES == 4, "the item -> plane table above");
     // the current triple: loads (unconditional, from clamped addresses; the zero padding is selected when the value is used) ...
     auto ring_load = [&]() {
 #pragma unroll
@@ -261,14 +277,12 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     auto ring_store = [&]() {
 #pragma unroll
         for (int k = 0; k < NCF_KRING; ++k) {
-            if ((okbits >> k) & 1u) {
-                const bool inside = iin[k] && ((okbits >> (8 + k)) & 1u);
-                const int dst = idst[k] + lrow[k];
-                const float x0 = (inside && okd0) ? q0v[k] * xscale : 0.f, x1 = (inside && okd1) ? q1v[k] * xscale : 0.f;
-                const unsigned h = npk(x0, x1);
-                *(unsigned *)(Xs + dst) = h;
-                *(unsigned *)(Xs + XPLANE + dst) = npk(x0 - npk_lo(h), x1 - npk_hi(h));
-            }
+            const float f = iin[k] ? 1.f : 0.f;                // (scalar) the whole plane lies outside the volume: zeros
+            const int dst = idst[k] + lrow[k];
+            const float x0 = q0v[k] * m0v[k] * f, x1 = q1v[k] * m1v[k] * f;
+            const unsigned h = npk(x0, x1);
+            *(unsigned *)(Xs + dst) = h;
+            *(unsigned *)(Xs + XPLANE + dst) = npk(x0 - npk_lo(h), x1 - npk_hi(h));
         }
     };
 
@@ -319,8 +333,7 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     __syncthreads();
     NT(0)
     int pending = -1;                         // output slice whose last contribution the previous strip added
-    for (int strip = 0; strip < nstrips; ++strip) {
-        const int row = strip / nbp, j = strip - row * nbp;
+    for (int strip = 0, row = 0, j = 0; strip < nstrips; ++strip, (j + 1 < nbp ? ++j : (j = 0, ++row))) {
         const int ap = ap_first + row, bp = strip_bp(ap, j);
         const bool more = strip + 1 < nstrips, same_row = j + 1 < nbp;
         const int dir = (ap & 1) ? -1 : 1;
@@ -388,23 +401,21 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
             for (int u = 0; u < 2; ++u) {
                 if (wave + NCF_WAVES * u >= nt1) break;               // (wave-uniform) the clamped copy is not stored
                 const int q0 = (wave + NCF_WAVES * u) * 64;
-                const bool okq = (s2ok >> (2 * u + kb5)) & 1u;
+                // positions outside the volume store zeros: the packed dwords are AND-ed with a lane mask (as a select of
+                // the sixteen values the compiler built eighteen branches per strip)
+                const unsigned keep = ((s2ok >> (2 * u + kb5)) & 1u) ? 0xffffffffu : 0u;
                 unsigned char *dst = Hs + (q0 + 2 * l31 + kb5 + 1) * 16;      // + 1: position -1 is slot 0
 #pragma unroll
                 for (int kh = 0; kh < 2; ++kh) {
-                    const nf4 sa = *(const nf4 *)(C1 + 8 * kh), sb = *(const nf4 *)(C1 + 8 * kh + 4);
-                    const nf4 ba = *(const nf4 *)(C1 + 16 + 8 * kh), bb = *(const nf4 *)(C1 + 16 + 8 * kh + 4);
                     float h[8];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        h[j] = okq ? fmaxf(fmaf(acc[u][8 * kh + j], sa[j], ba[j]), 0.f) : 0.f;
-                        h[4 + j] = okq ? fmaxf(fmaf(acc[u][8 * kh + 4 + j], sb[j], bb[j]), 0.f) : 0.f;
-                    }
+                    for (int j = 0; j < 8; ++j) h[j] = fmaxf(fmaf(acc[u][8 * kh + j], e1s[8 * kh + j], e1b[8 * kh + j]), 0.f);
                     unsigned p0[4], p1[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        p0[j] = npk(h[2 * j], h[2 * j + 1]);
-                        p1[j] = npk(h[2 * j] - npk_lo(p0[j]), h[2 * j + 1] - npk_hi(p0[j]));
+                        const unsigned hp = npk(h[2 * j], h[2 * j + 1]);
+                        p0[j] = hp & keep;
+                        p1[j] = npk(h[2 * j] - npk_lo(hp), h[2 * j + 1] - npk_hi(hp)) & keep;
                     }
                     *(nf4 *)(dst + kh * HKH) = (nf4){__uint_as_float(p0[0]), __uint_as_float(p0[1]), __uint_as_float(p0[2]), __uint_as_float(p0[3])};
                     *(nf4 *)(dst + kh * HKH + HPLANE) = (nf4){__uint_as_float(p1[0]), __uint_as_float(p1[1]), __uint_as_float(p1[2]), __uint_as_float(p1[3])};
