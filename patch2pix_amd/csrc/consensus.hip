@@ -180,10 +180,10 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     }
 
     for (int i = tid; i < 3 * YSLOT; i += NCF_THREADS) Ya[i] = 0.f;
-    for (int i = tid; i < 2 * 2 * 2; i += NCF_THREADS) {     // the pad slots before and after the hidden positions stay zero
-        const int pl = i >> 2, kh = (i >> 1) & 1, end = i & 1;
-        *(nf4 *)(Hs + pl * HPLANE + kh * HKH + (end ? (HNU - 1) * 16 : 0)) = (nf4){0.f, 0.f, 0.f, 0.f};
-    }
+    // The hidden planes start as zeros: the pad slots around the positions and every position outside the volume stay zero
+    // for the whole kernel (which positions those are depends on (c, d) only, not on the strip) -- their lanes store
+    // to the spare slot HNU instead (HN - HNU = 14 spare slots per channel half).
+    for (int i = tid; i < 2 * HPLANE / 16; i += NCF_THREADS) *(nf4 *)(Hs + i * 16) = (nf4){0.f, 0.f, 0.f, 0.f};
 
     const int a_hi = min(a0 + TA, a.d0);                     // outputs of the tile: [a0, a_hi)
     const int ap_first = max(a0 - 1, 0), ap_last = min(a0 + TA, a.d0 - 1);
@@ -195,18 +195,26 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     // again is behind the barrier between this strip's two layers.
     auto flush = [&](int aout) {
         float *slot = Ya + (aout % 3) * YSLOT;
-        for (int r = wave; r < TB * TC; r += NCF_WAVES) {
+        // 32-bit element offsets (a volume has < 2^31 cells): this lane's cell of the tile's row (b0, c0) of slice aout
+        const int ybase = (aout * a.d1 + b0) * (int)nB + c0 * a.d3 + dt0 + lane;
+        const bool lane_in = lane < TD && dt0 + lane < a.d3;
+        auto row = [&](int r) {
             const int bb = r / TC, ro = r - bb * TC;
-            const int ib = b0 + bb, ic = c0 + ro, id = dt0 + lane;
             if (lane < TD) {
                 float *cell = slot + bb * YROW + ro * P + lane + 1;
                 const float v = fmaxf(*cell + a.b2, 0.f);
                 *cell = 0.f;
-                if (ib < a.d1 && ic < a.d2 && id < a.d3) {
-                    float *dst = Y + ((size_t)aout * a.d1 + ib) * nB + (size_t)ic * a.d3 + id;
+                if (lane_in && b0 + bb < a.d1 && c0 + ro < a.d2) {
+                    float *dst = Y + (unsigned)(ybase + bb * (int)nB + ro * a.d3);
                     if (plain) *dst = v; else unsafeAtomicAdd(dst, v);
                 }
             }
+        };
+        if (FIXED) {
+#pragma unroll 2
+            for (int i = 0; i < 10; ++i) row(wave + NCF_WAVES * i);
+        } else {
+            for (int r = wave; r < TB * TC; r += NCF_WAVES) row(r);
         }
     };
 
@@ -291,6 +299,7 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     const int l31 = lane & 31, kb5 = lane >> 5;
     const int nt1 = (HROWS * P + 63) >> 6;
     int s2qh[2] = {0, 0};
+    int s2dst[2] = {0, 0};                                    // byte offset of this lane's hidden slot (position + 1), or of the spare slot
     unsigned s2ok = 0;                                        // bit 2 u + s: position q0(u) + 2 l31 + s is a cell of the volume
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -303,6 +312,7 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
             const bool ok = t < nt1 && rowh < HROWS && col <= TD + 1 && ic >= 0 && ic < a.d2 && id >= 0 && id < a.d3;
             s2ok |= (unsigned)ok << (2 * u + sp);
         }
+        s2dst[u] = (((s2ok >> (2 * u + kb5)) & 1u) ? q0 + 2 * l31 + kb5 + 1 : HNU) * 16;
     }
     // layer 2: hidden offsets of the lane's K block per step
     const int row16 = lane & 15, kb4 = lane >> 4;
@@ -400,22 +410,22 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (wave + NCF_WAVES * u >= nt1) break;               // (wave-uniform) the clamped copy is not stored
-                const int q0 = (wave + NCF_WAVES * u) * 64;
-                // positions outside the volume store zeros: the packed dwords are AND-ed with a lane mask (as a select of
-                // the sixteen values the compiler built eighteen branches per strip)
-                const unsigned keep = ((s2ok >> (2 * u + kb5)) & 1u) ? 0xffffffffu : 0u;
-                unsigned char *dst = Hs + (q0 + 2 * l31 + kb5 + 1) * 16;      // + 1: position -1 is slot 0
+                unsigned char *dst = Hs + s2dst[u];                  // (a position outside the volume: the spare slot)
 #pragma unroll
                 for (int kh = 0; kh < 2; ++kh) {
                     float h[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) h[j] = fmaxf(fmaf(acc[u][8 * kh + j], e1s[8 * kh + j], e1b[8 * kh + j]), 0.f);
+                    for (int j = 0; j < 4; ++j) {
+                        const nf2 av = {acc[u][8 * kh + 2 * j], acc[u][8 * kh + 2 * j + 1]};
+                        const nf2 sv = {e1s[8 * kh + 2 * j], e1s[8 * kh + 2 * j + 1]}, bv = {e1b[8 * kh + 2 * j], e1b[8 * kh + 2 * j + 1]};
+                        const nf2 hv = __builtin_elementwise_fma(av, sv, bv);
+                        h[2 * j] = fmaxf(hv[0], 0.f); h[2 * j + 1] = fmaxf(hv[1], 0.f);
+                    }
                     unsigned p0[4], p1[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const unsigned hp = npk(h[2 * j], h[2 * j + 1]);
-                        p0[j] = hp & keep;
-                        p1[j] = npk(h[2 * j] - npk_lo(hp), h[2 * j + 1] - npk_hi(hp)) & keep;
+                        p0[j] = npk(h[2 * j], h[2 * j + 1]);
+                        p1[j] = npk(h[2 * j] - npk_lo(p0[j]), h[2 * j + 1] - npk_hi(p0[j]));
                     }
                     *(nf4 *)(dst + kh * HKH) = (nf4){__uint_as_float(p0[0]), __uint_as_float(p0[1]), __uint_as_float(p0[2]), __uint_as_float(p0[3])};
                     *(nf4 *)(dst + kh * HKH + HPLANE) = (nf4){__uint_as_float(p1[0]), __uint_as_float(p1[1]), __uint_as_float(p1[2]), __uint_as_float(p1[3])};
@@ -433,6 +443,46 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
             float *ydst = Ya + ((aout + 3) % 3) * YSLOT + (bout - b0) * YROW;
             // two m-tiles at a time (independent accumulators), the fragments of step st + 1 in flight during the MFMAs of step st
             const bool yalign = (YROW & 3) == 0;               // every (slot, plane) row of the accumulators starts 16-byte aligned
+            if (FIXED) {
+                // TC * P = 352 = 22 whole m-tiles: wave w takes the pairs (w + 8 i, w + 8 i + 4), i = 0 .. 2; the second tile of
+                // the last pair does not exist for waves 2 and 3 (they multiply the first one twice and drop the copy)
+                const unsigned char *hl = Hs + row16 * 16;
+                float *yl = ydst + 4 * kb4;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int qa = (wave + 8 * i) * 16;
+                    const bool has_b = i < 2 || wave < 2;
+                    const int qb = has_b ? qa + 64 : qa;
+                    const unsigned char *ha = hl + qa * 16, *hb = hl + qb * 16;
+                    nf4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+                    nf4 fr[2][4];
+                    auto frags3 = [&](int st, nf4 (&d)[4]) {
+                        d[0] = *(const nf4 *)(ha + s3off[st]); d[1] = *(const nf4 *)(ha + s3off[st] + HPLANE);
+                        d[2] = *(const nf4 *)(hb + s3off[st]); d[3] = *(const nf4 *)(hb + s3off[st] + HPLANE);
+                    };
+                    frags3(0, fr[0]);
+#pragma unroll
+                    for (int st = 0; st < 5; ++st) {
+                        nf4 (&c)[4] = fr[st & 1];
+                        if (st < 4) frags3(st + 1, fr[(st + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        accA = NCF_MFMA16(c[1], w2[st][0], accA); accB = NCF_MFMA16(c[3], w2[st][0], accB);
+                        accA = NCF_MFMA16(c[0], w2[st][1], accA); accB = NCF_MFMA16(c[2], w2[st][1], accB);
+                        accA = NCF_MFMA16(c[0], w2[st][0], accA); accB = NCF_MFMA16(c[2], w2[st][0], accB);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (lane_ok) {
+                        nf4 va = *(nf4 *)(yl + qa);
+                        va += accA * yun;
+                        *(nf4 *)(yl + qa) = va;
+                        if (has_b) {
+                            nf4 vb = *(nf4 *)(yl + qb);
+                            vb += accB * yun;
+                            *(nf4 *)(yl + qb) = vb;
+                        }
+                    }
+                }
+            } else
             for (int t = wave; t < nt2; t += 2 * NCF_WAVES) {
                 const int qa = t * 16, qb = qa + NCF_WAVES * 16;
                 const unsigned char *ha = Hs + min(qa + row16, TC * P - 1) * 16, *hb = Hs + min(qb + row16, TC * P - 1) * 16;
