@@ -254,14 +254,15 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     bool iin[NCF_KRING];
     // (three plane descriptors per strip; item k of wave w belongs to plane min((w + 4 k) / 6, 2): 0, w >= 2, 1, 2, 2)
     const bool k1_second = wave >= 2;
-    auto triple = [&](int pa, int pb, bool along_a) {
+    auto rot3 = [](int m, int i) { return m + i >= 3 ? m + i - 3 : m + i; };      // (m + i) mod 3 for m in 0..2, i in 0..2
+    // ma, mb = ring slot (pa mod 3, pb mod 3) of the triple's first plane; the others follow cyclically
+    auto triple = [&](int pa, int pb, bool along_a, int ma, int mb) {
         int src3[3], dst3[3];
         bool in3[3];
-        const int ma = (pa + 3) % 3, mb = (pb + 3) % 3;          // ring slot of the first plane; the others follow cyclically
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int ia = along_a ? pa + i : pa, ib = along_a ? pb : pb + i;
-            const int sa = along_a ? (ma + i >= 3 ? ma + i - 3 : ma + i) : ma, sb = along_a ? mb : (mb + i >= 3 ? mb + i - 3 : mb + i);
+            const int sa = along_a ? rot3(ma, i) : ma, sb = along_a ? mb : rot3(mb, i);
             src3[i] = clampi(ia, 0, a.d0 - 1) * sA + clampi(ib, 0, a.d1 - 1) * sB;
             in3[i] = ia >= 0 && ia < a.d0 && ib >= 0 && ib < a.d1;
             dst3[i] = (sa * 3 + sb) * XROWS * P * 2;
@@ -277,8 +278,8 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     auto ring_load = [&]() {
 #pragma unroll
         for (int k = 0; k < NCF_KRING; ++k) {
-            const int src = isrc[k] + crow[k];
-            q0v[k] = X[src + coff0]; q1v[k] = X[src + coff1];
+            const int src = isrc[k] + crow[k];                 // (non-negative, < 2^31: unsigned offsets need no sign extension)
+            q0v[k] = X[(unsigned)(src + coff0)]; q1v[k] = X[(unsigned)(src + coff1)];
         }
     };
     // ... and their conversion to two fp16 planes of X * 2^12 (adjacent columns packed: one 4-byte store per plane)
@@ -314,8 +315,10 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
         }
         s2dst[u] = (((s2ok >> (2 * u + kb5)) & 1u) ? q0 + 2 * l31 + kb5 + 1 : HNU) * 16;
     }
+    const unsigned char *s2x[2] = {Xs + s2qh[0] * 2, Xs + s2qh[1] * 2};      // this lane's window origin inside a staged plane
     // layer 2: hidden offsets of the lane's K block per step
     const int row16 = lane & 15, kb4 = lane >> 4;
+    const int l2da3 = (lane & 15) / 3 % 3, l2da = (lane & 15) < 9 ? (lane & 15) / 3 : 64, l2db = (lane & 15) < 9 ? (lane & 15) % 3 : 64;
     int s3off[5];
 #pragma unroll
     for (int st = 0; st < 5; ++st) {
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
     {
         const int bq = strip_bp(ap_first, 0);
         for (int i = 0; i < 3; ++i) {         // all nine planes of the first strip
-            triple(ap_first - 1, bq - 1 + i, true);
+            triple(ap_first - 1, bq - 1 + i, true, (ap_first + 2) % 3, (bq + 2 + i) % 3);
             ring_load();
             ring_store();
         }
@@ -352,13 +355,16 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
         if (pending >= 0) flush(pending);
         pending = -1;
         NT(5)
-        triple(npa, npb, same_row);
+        // ring slots by rotation from the two of this strip: am = (a' - 1) mod 3, bm = (b' - 1) mod 3.  The next triple starts at
+        // a' - 1 (same slot as am) or a' + 2 (= a' - 1 mod 3), and at b' + 2 dir or b' - 1
+        const int am = (ap + 2) % 3, bm = (bp + 2) % 3;
+        triple(npa, npb, same_row, am, same_row ? rot3(bm, dir > 0 ? 0 : 2) : bm);
         if (more) ring_load();                                // in flight during both layers of this strip
         // ---------------- S2: layer 1 -> hidden planes
         {
             // ring slots of the planes a' - 1 .. a' + 1 and b' - 1 .. b' + 1 (element offsets)
-            const int sa0 = ((ap + 2) % 3) * 3 * XROWS * P, sa1 = ((ap + 3) % 3) * 3 * XROWS * P, sa2 = ((ap + 4) % 3) * 3 * XROWS * P;
-            const int sl0 = ((bp + 2) % 3) * XROWS * P, sl1 = ((bp + 3) % 3) * XROWS * P, sl2 = ((bp + 4) % 3) * XROWS * P;
+            const int sa0 = am * 3 * XROWS * P, sa1 = rot3(am, 1) * 3 * XROWS * P, sa2 = rot3(am, 2) * 3 * XROWS * P;
+            const int sl0 = bm * XROWS * P, sl1 = rot3(bm, 1) * XROWS * P, sl2 = rot3(bm, 2) * XROWS * P;
             auto xoff = [&](int gq) {                         // tap group (da, db, dc) -> element offset of its plane row
                 const int da = gq / 9, db = (gq / 3) % 3, dc = gq % 3;
                 return (da == 0 ? sa0 : da == 1 ? sa1 : sa2) + (db == 0 ? sl0 : db == 1 ? sl1 : sl2) + dc * P;
@@ -381,8 +387,8 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int p = 0; p < 2; ++p) {
-                        const unsigned *x0 = (const unsigned *)(Xs + p * XPLANE + (o0 + s2qh[u]) * 2);
-                        const unsigned *x1 = (const unsigned *)(Xs + p * XPLANE + (o1 + s2qh[u]) * 2);
+                        const unsigned *x0 = (const unsigned *)(s2x[u] + p * XPLANE + o0 * 2);      // one shift-add per address
+                        const unsigned *x1 = (const unsigned *)(s2x[u] + p * XPLANE + o1 * 2);
                         d[u][p] = (nf4){__uint_as_float(x0[0]), __uint_as_float(x0[1]), __uint_as_float(x1[0]), __uint_as_float(x1[1])};
                     }
             };
@@ -437,10 +443,12 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
         NT(2)
         // ---------------- S3: layer 2, contributions of the strip to the 3 x 3 output planes around it
         {
-            const int n = lane & 15, da = n / 3, db = n - 3 * da;
-            const int aout = ap - da + 1, bout = bp - db + 1;
-            const bool lane_ok = n < 9 && aout >= a0 && aout < a_hi && bout >= b0 && bout < min(b0 + TB, a.d1);
-            float *ydst = Ya + ((aout + 3) % 3) * YSLOT + (bout - b0) * YROW;
+            // lane n = lane & 15 adds into output plane (a' - da + 1, b' - db + 1), (da, db) = (n / 3, n % 3) (l2da, l2db: per-lane
+            // constants, 64 for the unused columns n >= 9); accumulator slot (a' + 4 - da) mod 3 from the scalar (a' + 4) mod 3
+            const int aout = ap + 1 - l2da, bout = bp + 1 - l2db;
+            const bool lane_ok = aout >= a0 && aout < a_hi && bout >= b0 && bout < min(b0 + TB, a.d1);
+            const int apm = rot3(am, 2), sl3 = apm - l2da3;
+            float *ydst = Ya + (sl3 < 0 ? sl3 + 3 : sl3) * YSLOT + (bout - b0) * YROW;
             // two m-tiles at a time (independent accumulators), the fragments of step st + 1 in flight during the MFMAs of step st
             const bool yalign = (YROW & 3) == 0;               // every (slot, plane) row of the accumulators starts 16-byte aligned
             if (FIXED) {
