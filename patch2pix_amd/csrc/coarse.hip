@@ -231,32 +231,41 @@ __global__ __launch_bounds__(256) void corr_pool_kernel(const unsigned short *__
         if (it + 1 < nk) store(cx + ((it + 1) & 1) * CX_STAGE);     // the other stage: everybody left it at the last barrier
         __syncthreads();
     }
-    {                                        // the planes carried 2^12 each
-        constexpr float inv = 1.0f / (CORR_FP16_SCALE * CORR_FP16_SCALE);
+    // the planes carried 2^12 each: the accumulators hold 2^24 x the correlation (undone exactly at the stores; a maximum
+    // commutes with the positive power of two)
+    constexpr float inv = 1.0f / (CORR_FP16_SCALE * CORR_FP16_SCALE);
+
+    // accumulator element r of lane: row = (r&3) + 8*(r>>2) + 4*half, col = l31
+    if (KS == 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int tr = rowA0 + wr * 64 + i * 32, tc = rowB0 + wc * 64 + j * 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = tr + (r & 3) + 8 * (r >> 2) + 4 * half, col = tc + l31;
+                    if (row < nA && col < nB) P[(size_t)row * nB + col] = acc[i][j][r] * inv;
+                }
+            }
+        return;
+    }
+    // k = 2: a pooling cell is a 4x4 block: rows = (i,j) of A in regs 4g..4g+3, cols = (k,l) of B in 4 adjacent lanes.
+    // First maximum in the order s = row_in_cell*4 + col_in_cell.  The exchange inside a quad of lanes is two DPP moves per
+    // value (quad_perm; __shfl_xor goes through the LDS crossbar and is waited for: 64 of them were a third of a tile's
+    // time), the pooled offsets are 32-bit (a pooled volume has < 2^31 cells), the bounds of a tile are checked once.
+    {
+        const int nAc = nA >> 2, nBc = nB >> 2;
+        const int crow0 = ((rowA0 + wr * 64) >> 2) + half, ccol0 = (rowB0 + wc * 64 + l31) >> 2;
+        const bool writer = (lane & 3) == 0;
+        const bool full = ((rowA0 + CT) >> 2) <= nAc && ((rowB0 + CT) >> 2) <= nBc;      // (wave-uniform) no cell of the tile is outside
+        // all sixteen cells of the lane's quad first (the exchanges need every lane), then ONE masked block of stores
+        float pbest[2][2][4];
+        int ps[2][2][4];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
-    }
-
-    // accumulator element r of lane: row = (r&3) + 8*(r>>2) + 4*half, col = l31
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int tr = rowA0 + wr * 64 + i * 32, tc = rowB0 + wc * 64 + j * 32;
-            if (KS == 1) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = tr + (r & 3) + 8 * (r >> 2) + 4 * half, col = tc + l31;
-                    if (row < nA && col < nB) P[(size_t)row * nB + col] = acc[i][j][r];
-                }
-            } else {
-                // k = 2: a pooling cell is a 4x4 block: rows = (i,j) of A in regs 4g..4g+3, cols = (k,l)
-                // of B in 4 adjacent lanes.  First maximum in the order s = row_in_cell*4 + col_in_cell.
-                const int nAc = nA >> 2, nBc = nB >> 2;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float best = acc[i][j][4 * g];
@@ -267,22 +276,37 @@ __global__ __launch_bounds__(256) void corr_pool_kernel(const unsigned short *__
                         if (v > best) { best = v; s = r; }
                     }
                     s = s * 4 + (lane & 3);
-#pragma unroll
-                    for (int m = 1; m <= 2; m <<= 1) {
-                        const float ov = __shfl_xor(best, m);
-                        const int os = __shfl_xor(s, m);
+                    {
+                        const float ov = __uint_as_float(P2P_SWAP_ADJACENT(__float_as_uint(best)));
+                        const int os = (int)P2P_SWAP_ADJACENT((unsigned)s);
                         if (ov > best || (ov == best && os < s)) { best = ov; s = os; }
                     }
-                    if ((lane & 3) == 0) {
-                        const int crow = (tr >> 2) + 2 * g + half, ccol = (tc + l31) >> 2;
-                        if (crow < nAc && ccol < nBc) {
-                            P[(size_t)crow * nBc + ccol] = best;
-                            if (delta) delta[(size_t)crow * nBc + ccol] = (uint8_t)s;
+                    {
+                        const float ov = __uint_as_float(P2P_SWAP_PAIRS(__float_as_uint(best)));
+                        const int os = (int)P2P_SWAP_PAIRS((unsigned)s);
+                        if (ov > best || (ov == best && os < s)) { best = ov; s = os; }
+                    }
+                    pbest[i][j][g] = best * inv;
+                    ps[i][j][g] = s;
+                }
+        if (writer) {
+            float *Pl = P + (unsigned)(crow0 * nBc + ccol0);
+            uint8_t *Dl = delta ? delta + (unsigned)(crow0 * nBc + ccol0) : nullptr;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int dr = 8 * i + 2 * g, dc = 8 * j;
+                        if (full || (crow0 + dr < nAc && ccol0 + dc < nBc)) {
+                            const unsigned at = (unsigned)(dr * nBc + dc);
+                            Pl[at] = pbest[i][j][g];
+                            if (Dl) Dl[at] = (uint8_t)ps[i][j][g];
                         }
                     }
-                }
-            }
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -47,6 +47,9 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 #ifndef P2P_SWAP_ADJACENT          // exchange a 32-bit value with the neighbouring lane (lane ^ 1): one DPP move, no LDS crossbar
 #define P2P_SWAP_ADJACENT(v) ((unsigned)__builtin_amdgcn_mov_dpp((int)(v), 0xB1, 0xF, 0xF, true))      /* quad_perm [1,0,3,2] */
 #endif
+#ifndef P2P_SWAP_PAIRS             // the same with the lane two further (lane ^ 2)
+#define P2P_SWAP_PAIRS(v) ((unsigned)__builtin_amdgcn_mov_dpp((int)(v), 0x4E, 0xF, 0xF, true))         /* quad_perm [2,3,0,1] */
+#endif
 #ifndef P2P_LANE_ID                // lane index inside the wave, recomputed from the hardware (v_mbcnt) instead of kept in a register
 #define P2P_LANE_ID() ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
 #endif

@@ -28,6 +28,7 @@
 #define P2P_OPAQUE_S(v) asm volatile("" : "+r"(v))
 #define P2P_OPAQUE_V4(v) asm volatile("" : "+x"(v))
 #define P2P_SWAP_ADJACENT(v) ((unsigned)__shfl_xor((int)(v), 1))
+#define P2P_SWAP_PAIRS(v) ((unsigned)__shfl_xor((int)(v), 2))
 #define P2P_LANE_ID() ((int)(hipemu::ctx().thread.x & 63))
 #define P2P_DYN_SHARED(T, name) T *name = (T *)hipemu::dynamic_shared()
 #define P2P_WAVE_SYNC() do { char z_ = 0; (void)hipemu::wave_gather(&z_, 1); } while (0)   /* the lanes are fibers: rendezvous */
