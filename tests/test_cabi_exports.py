@@ -92,3 +92,18 @@ def test_plain_c_example_builds_and_reports_missing_device(tmp_path):
     if not torch.cuda.is_available():
         res = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
         assert res.returncode == 3 and "no HIP device" in res.stderr
+
+
+def test_library_reads_no_environment_variables():
+    """no global mutable state besides the weight handles.  Modes and tiles are per-handle setters
+    (p2p_regressor_set_mode, p2p_ncn_set_tile, p2p_conv_set_tile); the environment variables of the tools are mapped onto
+    them by the Python host layer, the library itself calls no getenv."""
+    import glob
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hits = []
+    for f in glob.glob(os.path.join(root, "patch2pix_amd", "csrc", "*.h*")):
+        for i, line in enumerate(open(f, errors="replace"), 1):
+            if "getenv" in line:
+                hits.append(f"{os.path.basename(f)}:{i}")
+    assert not hits, hits

@@ -121,3 +121,28 @@ def test_backbone_pack_cache_signature_follows_the_module():
     net._hip_trunk_cache, net._hip_sig = object(), s4          # the cache itself is not copied or pickled
     twin = copy.deepcopy(net)
     assert not hasattr(twin, "_hip_trunk_cache") and not hasattr(twin, "_hip_sig")
+
+
+def test_homography_substitute_metric():
+    """tools/hpatches_substitute.py (BASELINE configs[2] stand-in): the seeded homography maps the four corners as drawn, and
+    MMA@3px counts a match iff its first point, mapped by H, lands within 3 px of the second."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import hpatches_substitute as hs
+    rng = np.random.RandomState(3)
+    H = hs.random_homography(rng, 640, 480)
+    assert abs(H[2, 2] - 1.0) < 1e-12
+    pts = np.array([[10.0, 20.0], [600.0, 400.0], [320.0, 240.0], [5.0, 470.0]])
+    q = np.concatenate([pts, np.ones((4, 1))], 1) @ H.T
+    q = q[:, :2] / q[:, 2:3]
+    good = np.concatenate([pts, q + [[1.0, -1.5], [0.0, 0.0], [2.0, 2.0], [0.5, 0.5]]], 1)
+    assert hs.mma(good, H) == 1.0
+    bad = good.copy()
+    bad[0, 2] += 3.5                                   # 3.5 px beyond the 1 px offset of the first match
+    bad[3, 3] -= 10.0
+    assert hs.mma(bad, H) == 0.5
+    assert hs.mma(np.zeros((0, 4)), H) == 0.0
+    corners = np.array([[0, 0, 1], [640, 0, 1], [640, 480, 1], [0, 480, 1]], dtype=float) @ H.T
+    corners = corners[:, :2] / corners[:, 2:3]
+    assert np.abs(corners - [[0, 0], [640, 0], [640, 480], [0, 480]]).max() <= 0.12 * 640 + 1e-6
