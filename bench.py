@@ -3,7 +3,8 @@
 480x640, ptmax=400).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: either under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`, or as the
+  plain command above, which then starts its own N ranks that way on 127.0.0.1 -- `self_launch`)
 
 A step = one pass of the hot path over a batch of image pairs whose feature pyramids are already resident in
 HBM: coarse stage (normalise, 4-D correlation + pool, mutual matching, consensus, matches) ->
@@ -87,7 +88,47 @@ def parse():
     ap.add_argument("--pairs", type=int, default=0,
                     help="stream mode (BASELINE configs[3]): this many seeded pairs in total, sharded pair_id %% world, "
                          "generated on the device chunk by chunk; --steps / --warmup are ignored")
+    ap.add_argument("--rendezvous-check", action="store_true",
+                    help="only initialise the ranks (RCCL, or gloo without a GPU), all_gather their ranks, print them and exit")
     return ap.parse_args()
+
+
+def self_launch(ngpus):
+    """`python bench.py --gpus N` as a PLAIN command (no WORLD_SIZE in the environment): become
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <argv>`,
+    one rank per GPU; the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* like under an external launcher."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL between processes needs it on these hosts
+    env.setdefault("OMP_NUM_THREADS", "4")
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
+def rendezvous_check(world, rank, local_rank):
+    """--rendezvous-check: the ranks find each other and exchange one number each (what the first seconds of a real run do)."""
+    import torch.distributed as dist
+    use_gpu = torch.cuda.is_available() and torch.cuda.device_count() >= world
+    if use_gpu:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dev = torch.device("cpu")
+        dist.init_process_group("gloo")
+    t = torch.tensor([float(rank)], device=dev, dtype=torch.float64)
+    allt = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(allt, t)
+    if rank == 0:
+        print(json.dumps({"rendezvous": "ok", "backend": dist.get_backend(), "world": world,
+                          "ranks": [int(x.item()) for x in allt]}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def source_hash():
@@ -481,11 +522,19 @@ def main():
     if args.pairs_per_step:
         cfg["pairs_per_step"] = args.pairs_per_step
     H, W, PTMAX, B = cfg["H"], cfg["W"], cfg["ptmax"], cfg["pairs_per_step"]
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)                   # does not return: the plain command becomes its own launcher
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus must agree")
+    if args.rendezvous_check:
+        if world > 1:
+            rendezvous_check(world, rank, local_rank)
+        elif rank == 0:
+            print(json.dumps({"rendezvous": "ok", "backend": None, "world": 1, "ranks": [0]}), flush=True)
+        return
     # host side of a rank is one Python thread plus small torch-CPU ops: keep N ranks from oversubscribing the host, and
     # every thread team well inside the CPU quota (a team as wide as the quota, spinning after a parallel region, gets the
     # whole process throttled for the rest of the scheduler period: one such stall costs a 20-step run 7 %)

@@ -189,3 +189,21 @@ def test_pair_stream_on_two_ranks(num_pairs, chunk, gather_every):
         fins = [i for i, e in enumerate(log) if e[0] == "finish"]
         assert len(subs) == len(fins) and all(e[1] == f[1] for e, f in zip([log[i] for i in subs], [log[i] for i in fins]))
         assert all(subs[k + 1] < fins[k] for k in range(len(fins) - 1))
+
+
+def test_plain_bench_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2` as a PLAIN command (no launcher, no WORLD_SIZE): bench.self_launch re-executes it under
+    torch.distributed.run with two ranks on 127.0.0.1; --rendezvous-check stops after the ranks have found each other
+    (gloo stands in for RCCL without a GPU)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-check"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["rendezvous"] == "ok" and out["world"] == 2 and out["ranks"] == [0, 1]
