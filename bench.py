@@ -58,9 +58,6 @@ MODES = {
                    peak_note="peak = 2500 TFLOP/s dense fp16 MFMA / 3 MFMA products per fp32 product"),
     "f32": dict(kernel="regress_kernel", products=None, peak=PEAK_F32_MFMA_TFLOPS, dtype="f32",
                 peak_note="peak = 157.3 TFLOP/s dense fp32 MFMA"),
-    "bf16x2": dict(kernel="regress_split_kernel", products=3, peak=PEAK_BF16_MFMA_TFLOPS / 3.0,
-                   dtype="bf16x2 (REDUCED precision: f32 operands split hi+lo = 16 significant bits, f32 accumulate)",
-                   peak_note="peak = 2500 TFLOP/s dense bf16 MFMA / 3 MFMA products per fp32 product"),
 }
 
 

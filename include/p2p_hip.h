@@ -81,14 +81,17 @@ void p2p_regressor_destroy(p2p_regressor *reg);
  *                      fp32 accumulation; the scales are undone exactly.  As accurate as P2P_REGRESS_F32 against
  *                      an fp64 evaluation at 5.3x its matrix-core ceiling;
  *   P2P_REGRESS_F32    v_mfma_f32_32x32x2_f32, bit-identical to an fp32 fma chain;
- *   P2P_REGRESS_BF16X2 reduced precision, opt-in only: two bf16 per operand (16 significant bits), three
- *                      products; regressed coordinates within ~2.5e-4 px of an fp64 evaluation.
+ *   P2P_REGRESS_FP16X2W the same arithmetic with the second convolution (3x3, stride 1 on the 8x8 map) evaluated as
+ *                      Winograd F(2x2, 3x3): 16 batched GEMMs over the transformed tiles of ALL proposals (2.25x fewer
+ *                      matrix-core passes; the transforms are exact up to fp32 rounding, transformed filters computed in
+ *                      fp64 at pack time) -- three launches per regressor level instead of one, and a larger scratch
+ *                      buffer (the transformed conv2 input of up to 2048 proposals, 512 KiB each).
  * New handles start in P2P_REGRESS_DEFAULT (the library reads no environment variables; the Python host layer maps
  * P2P_REGRESS_MODE onto p2p_regressor_set_mode).  Only the weight stream of the mode in use is packed and uploaded;
  * p2p_regressor_set_mode builds another mode's on its first selection (host-side packing + one upload).   */
 #define P2P_REGRESS_F32     0
-#define P2P_REGRESS_BF16X2  1
 #define P2P_REGRESS_FP16X2  3
+#define P2P_REGRESS_FP16X2W 4
 #define P2P_REGRESS_DEFAULT P2P_REGRESS_FP16X2
 int p2p_regressor_set_mode(p2p_regressor *reg, int mode);
 int p2p_regressor_get_mode(const p2p_regressor *reg);

@@ -110,7 +110,7 @@ p2p_absmax_batch = _sig("p2p_absmax_batch", ctypes.c_int, [ctypes.c_void_p, ctyp
 
 p2p_regressor_set_mode = _sig("p2p_regressor_set_mode", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int])
 p2p_regressor_get_mode = _sig("p2p_regressor_get_mode", ctypes.c_int, [ctypes.c_void_p])
-REGRESS_MODES = {"f32": 0, "bf16x2": 1, "fp16x2": 3}
+REGRESS_MODES = {"f32": 0, "fp16x2": 3, "fp16x2w": 4}
 
 EXPORTS = ["p2p_version", "p2p_last_error", "p2p_ncn_create", "p2p_ncn_destroy", "p2p_ncn_set_tile", "p2p_regressor_create",
            "p2p_regressor_destroy", "p2p_coarse_workspace_bytes", "p2p_coarse_forward", "p2p_coarse_forward_batch",

@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["api.hip", "backbone.hip", "coarse.hip", "consensus.hip", "filter.hip", "regress.hip", "regress_split.hip", "regress_h2.hip"]
+SOURCES = ["api.hip", "backbone.hip", "coarse.hip", "consensus.hip", "filter.hip", "regress.hip", "regress_h2.hip", "regress_wino.hip"]
 LIB = os.path.join(CSRC, "libp2p_hip.so")
 
 
@@ -58,30 +58,53 @@ def build(force=False, verbose=True):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
-    for src in SOURCES:
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+    headers = [d for d in _deps() if d.endswith(".h")]
+
+    def compile_one(src):
+        """One translation unit; skipped when the object on disk was built from the same source + headers + flags."""
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
                "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
+        h = hashlib.sha256(" ".join(cmd[1:-3]).encode())
+        for d in [os.path.join(CSRC, src)] + headers:
+            h.update(os.path.basename(d).encode())
+            h.update(open(d, "rb").read())
+        stamp, key = obj + ".srchash", h.hexdigest()
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == key:
+            return obj, ""
+        if os.path.exists(stamp):
+            os.remove(stamp)
         res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        lines = [" ".join(cmd)] if verbose else []
         report = _resource_report(res.stdout)
         other = [l for l in res.stdout.splitlines() if "-Rpass-analysis" not in l and "remark:" not in l and l.strip()
                  and "|" not in l[:12] and not l.lstrip().startswith("^") and "__global__" not in l]
         if other and (verbose or res.returncode):
-            print("\n".join(other), flush=True)
+            lines += other
         if res.returncode:
+            print("\n".join(lines), flush=True)
             raise subprocess.CalledProcessError(res.returncode, cmd)
         for name, usage in report.items():
             if verbose:
-                print(f"    {name}: {usage.get('VGPRs', '?')} VGPR, scratch {usage.get('ScratchSize [bytes/lane]', '?')} B/lane",
-                      flush=True)
+                lines.append(f"    {name}: {usage.get('VGPRs', '?')} VGPR + {usage.get('AGPRs', '?')} AGPR, "
+                             f"scratch {usage.get('ScratchSize [bytes/lane]', '?')} B/lane")
             # Register spills are a hard error: kernels that touch scratch memory produced wrong results /
             # memory faults on the MI355X boxes (hipcc 7.2 code objects under torch's bundled HIP 7.0 runtime).
             if int(usage.get("ScratchSize [bytes/lane]", "0")) != 0:
+                print("\n".join(lines), flush=True)
                 raise RuntimeError(f"{src}: kernel {name} spills to scratch ({usage}); restructure it until it does not")
-        objs.append(obj)
+        with open(stamp, "w") as f:
+            f.write(key)
+        return obj, "\n".join(lines)
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        results = list(ex.map(compile_one, SOURCES))
+    objs = [o for o, _ in results]
+    for _, text in results:
+        if text:
+            print(text, flush=True)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -57,6 +57,15 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 #define P2P_DYN_SHARED(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
 #endif
 
+#ifndef P2P_GLOBAL_LOAD_LDS16      // LDS-DMA: 16 bytes per lane, global `gptr + imm` (per lane) -> LDS `lptr + imm + 16 * lane` (lptr wave-uniform)
+#define P2P_GLOBAL_LOAD_LDS16(gptr, lptr, imm)                                                         \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),           \
+                                     (__attribute__((address_space(3))) void *)(lptr), 16, (imm), 0)
+#endif
+#ifndef P2P_WAIT_VMCNT             // counted wait for this wave's vector-memory operations (LDS-DMA pieces included)
+#define P2P_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#endif
+
 #ifndef P2P_WAVE_SYNC              // hand-over of LDS data between the lanes of ONE wave (LDS operations of a wave execute in order)
 #define P2P_WAVE_SYNC()                                        \
     do {                                                       \
@@ -87,15 +96,15 @@ struct p2p_ncn {
 
 struct p2p_regressor {
     float *dev;        // BatchNorm folds + FC layers (every mode)
-    float *dev_p, *dev_s, *dev_h;   // the convolution weights in the stream order of the f32 / bf16x2 / fp16x2 kernel; packed on
+    float *dev_p, *dev_h, *dev_w;   // the convolution weights in the stream order of the f32 / fp16x2 / fp16x2w kernels; packed on
                                     // the first selection of that mode (p2p_regressor_set_mode), null until then
     std::vector<float> conv1_w, conv2_w, bn1s_host, bn2s_host;   // host copies the packings are built from
     const float *wp1;  // f32: conv1 weights, MFMA-fragment order [8 waves][585 chunks][2][64 lanes][4]
     const float *wp2;  //      conv2 weights,                    [8][576][2][64][4]
-    const float *ws1, *ws2;     // bf16x2: the same weights split into bf16 hi/lo planes in 32x32x16 fragment order
     const float *wh1, *wh2;     // fp16x2: the same weights, scaled per output channel, split into two fp16 planes
     const float *bn1s_h, *bn2s_h;   // fp16x2: folded BN scales times the inverse of those weight (and activation) scales
-    int mode;                   // P2P_REGRESS_F32 | P2P_REGRESS_BF16X2 | P2P_REGRESS_FP16X2
+    const float *ww2, *bn2s_w;      // fp16x2w: conv2 as Winograd-transformed filter blocks (regress_wino.hip) + its BN scale
+    int mode;                   // P2P_REGRESS_F32 | P2P_REGRESS_FP16X2 | P2P_REGRESS_FP16X2W
     const float *bn1s, *bn1b;   // folded BN scale/shift [512]
     const float *bn2s, *bn2b;   // [512]
     const float *fc1t, *fc1b, *bnf1s, *bnf1b;   // fc1 as [128][512][4]; [512]

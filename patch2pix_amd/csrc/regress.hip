@@ -364,7 +364,18 @@ static int upload(const std::vector<float> &h, float **dev, const char *what) {
 static int ensure_mode(p2p_regressor *r, int mode) {
     auto al = [](size_t n) { return (n + 63) & ~size_t(63); };
     const float *c1 = r->conv1_w.data(), *c2 = r->conv2_w.data();
-    if (mode == P2P_REGRESS_FP16X2 && !r->dev_h) {
+    if (mode == P2P_REGRESS_FP16X2W && !r->dev_w) {
+        const int st0 = ensure_mode(r, P2P_REGRESS_FP16X2);      // conv1 runs from the fp16x2 stream
+        if (st0 != P2P_OK) return st0;
+        const size_t ob2 = al(WW2_FLOATS);
+        std::vector<float> h(ob2 + 512, 0.f);
+        std::vector<int> t2(512);
+        pack_wino_weights(c2, &h[0], t2.data());
+        for (int n = 0; n < 512; ++n) h[ob2 + n] = std::ldexp(r->bn2s_host[n], -t2[n]);
+        const int st = upload(h, &r->dev_w, "the Winograd filter blocks");
+        if (st != P2P_OK) return st;
+        r->ww2 = r->dev_w; r->bn2s_w = r->dev_w + ob2;
+    } else if (mode == P2P_REGRESS_FP16X2 && !r->dev_h) {
         const size_t o1 = 0, o2 = al(WH1_FLOATS), ob1 = o2 + al(WH2_FLOATS), ob2 = ob1 + 512;
         std::vector<float> h(ob2 + 512, 0.f);
         std::vector<int> t1(512), t2(512);
@@ -378,13 +389,6 @@ static int ensure_mode(p2p_regressor *r, int mode) {
         const int st = upload(h, &r->dev_h, "the fp16x2 weight streams");
         if (st != P2P_OK) return st;
         r->wh1 = r->dev_h + o1; r->wh2 = r->dev_h + o2; r->bn1s_h = r->dev_h + ob1; r->bn2s_h = r->dev_h + ob2;
-    } else if (mode == P2P_REGRESS_BF16X2 && !r->dev_s) {
-        const size_t o2 = al(WS1_FLOATS);
-        std::vector<float> h(o2 + al(WS2_FLOATS), 0.f);
-        pack_split_weights(c1, c2, &h[0], &h[o2]);
-        const int st = upload(h, &r->dev_s, "the bf16x2 weight streams");
-        if (st != P2P_OK) return st;
-        r->ws1 = r->dev_s; r->ws2 = r->dev_s + o2;
     } else if (mode == P2P_REGRESS_F32 && !r->dev_p) {
         const size_t o_wp1 = 0, o_wp2 = al(WP1_FLOATS);
         std::vector<float> h(o_wp2 + al(WP2_FLOATS), 0.f);
@@ -424,7 +428,7 @@ static int ensure_mode(p2p_regressor *r, int mode) {
 
 extern "C" int p2p_regressor_set_mode(p2p_regressor *reg, int mode) {
     P2P_REQUIRE(reg, P2P_EINVAL, "p2p_regressor_set_mode: null handle");
-    P2P_REQUIRE(mode == P2P_REGRESS_F32 || mode == P2P_REGRESS_BF16X2 || mode == P2P_REGRESS_FP16X2, P2P_EINVAL,
+    P2P_REQUIRE(mode == P2P_REGRESS_F32 || mode == P2P_REGRESS_FP16X2 || mode == P2P_REGRESS_FP16X2W, P2P_EINVAL,
                 "p2p_regressor_set_mode: unknown mode %d", mode);
     const int st = ensure_mode(reg, mode);
     if (st != P2P_OK) return st;
@@ -456,7 +460,7 @@ extern "C" int p2p_regressor_create(const p2p_regressor_params *p, p2p_regressor
     fold_bn(p->bn2, 512, &h[o_bn2s], &h[o_bn2b]);
     fold_bn(p->bnf1, 512, &h[o_bnf1s], &h[o_bnf1b]);
     fold_bn(p->bnf2, 256, &h[o_bnf2s], &h[o_bnf2b]);
-    // fc weights as [k/4][out][4] so that a wave reads 1 KiB contiguous per step (per-proposal tail of the f32 / bf16x2 kernels)
+    // fc weights as [k/4][out][4] so that a wave reads 1 KiB contiguous per step (per-proposal tail of the f32 kernel)
     for (int o = 0; o < 512; ++o)
         for (int k = 0; k < 512; ++k) h[o_fc1t + ((size_t)(k / 4) * 512 + o) * 4 + (k & 3)] = p->fc1_w[(size_t)o * 512 + k];
     for (int o = 0; o < 256; ++o)
@@ -473,8 +477,8 @@ extern "C" int p2p_regressor_create(const p2p_regressor_params *p, p2p_regressor
     if (st != P2P_OK) return st;
     p2p_regressor *r = new p2p_regressor();
     r->dev = dev;
-    r->dev_p = r->dev_s = r->dev_h = nullptr;
-    r->wp1 = r->wp2 = r->ws1 = r->ws2 = r->wh1 = r->wh2 = r->bn1s_h = r->bn2s_h = nullptr;
+    r->dev_p = r->dev_h = r->dev_w = nullptr;
+    r->ww2 = r->bn2s_w = r->wp1 = r->wp2 = r->wh1 = r->wh2 = r->bn1s_h = r->bn2s_h = nullptr;
     r->conv1_w.assign(p->conv1_w, p->conv1_w + (size_t)512 * 518 * 9);      // host copies: another mode's stream is packed on demand
     r->conv2_w.assign(p->conv2_w, p->conv2_w + (size_t)512 * 512 * 9);
     r->bn1s_host.assign(&h[o_bn1s], &h[o_bn1s] + 512);
@@ -498,14 +502,14 @@ extern "C" void p2p_regressor_destroy(p2p_regressor *reg) {
     if (!reg) return;
     (void)hipFree(reg->dev);
     if (reg->dev_p) (void)hipFree(reg->dev_p);
-    if (reg->dev_s) (void)hipFree(reg->dev_s);
     if (reg->dev_h) (void)hipFree(reg->dev_h);
+    if (reg->dev_w) (void)hipFree(reg->dev_w);
     delete reg;
 }
 
 static RegDev to_dev(const p2p_regressor *r) {
     RegDev d;
-    d.wp1 = r->wp1; d.wp2 = r->wp2; d.ws1 = r->ws1; d.ws2 = r->ws2; d.wh1 = r->wh1; d.wh2 = r->wh2;
+    d.ww2 = r->ww2; d.bn2s_w = r->bn2s_w; d.wp1 = r->wp1; d.wp2 = r->wp2; d.wh1 = r->wh1; d.wh2 = r->wh2;
     d.bn1s_h = r->bn1s_h; d.bn2s_h = r->bn2s_h; d.bn1s = r->bn1s; d.bn1b = r->bn1b; d.bn2s = r->bn2s; d.bn2b = r->bn2b;
     d.fc1t = r->fc1t; d.fc1b = r->fc1b; d.bnf1s = r->bnf1s; d.bnf1b = r->bnf1b;
     d.fc2t = r->fc2t; d.fc2b = r->fc2b; d.bnf2s = r->bnf2s; d.bnf2b = r->bnf2b; d.fc3 = r->fc3; d.fc3b = r->fc3b;
@@ -542,7 +546,7 @@ static int regress_batch_impl(const p2p_regressor *reg1, const p2p_regressor *re
             for (int j = 0; j < 4; ++j) P2P_REQUIRE(im[s]->level[j], P2P_EINVAL, "p2p_regress: null pyramid level");
         }
     }
-    const bool batched_fc = reg1->mode == P2P_REGRESS_FP16X2;
+    const bool batched_fc = reg1->mode == P2P_REGRESS_FP16X2 || reg1->mode == P2P_REGRESS_FP16X2W;
     if (batched_fc) {
         int most = 0;
         for (int i0 = 0; i0 < nitems; i0 += MAXB) {
@@ -551,7 +555,7 @@ static int regress_batch_impl(const p2p_regressor *reg1, const p2p_regressor *re
             most = std::max(most, n);
         }
         P2P_REQUIRE(workspace && workspace_bytes >= regress_ws_floats((size_t)most) * sizeof(float) && ((uintptr_t)workspace & 127) == 0,
-                    P2P_ENOMEM, "p2p_regress: workspace of %zu bytes (p2p_regress_workspace_bytes, 128-byte aligned) needed, got %zu",
+                    P2P_EINVAL, "p2p_regress: workspace of %zu bytes (p2p_regress_workspace_bytes, 128-byte aligned) needed, got %zu",
                     regress_ws_floats((size_t)most) * sizeof(float), workspace ? workspace_bytes : (size_t)0);
     }
     int dev = 0;
@@ -593,10 +597,11 @@ static int regress_batch_impl(const p2p_regressor *reg1, const p2p_regressor *re
         a.ws = (float *)workspace;      // launches of one call are ordered on the stream: they may share the scratch
         if (n > 0) {
             int st;
-            if (reg1->mode == P2P_REGRESS_FP16X2) {
+            a.wU = nullptr; a.hinv = nullptr; a.lvl0 = 0; a.p0 = 0; a.p1 = n; a.mblocks = 0;
+            if (reg1->mode == P2P_REGRESS_FP16X2W) {
+                st = launch_regress_wino(a, n, (hipStream_t)stream);
+            } else if (reg1->mode == P2P_REGRESS_FP16X2) {
                 st = launch_regress_h2(a, n, (hipStream_t)stream);
-            } else if (reg1->mode == P2P_REGRESS_BF16X2) {
-                st = launch_regress_split(a, n, (hipStream_t)stream);
             } else {
                 hipLaunchKernelGGL(regress_kernel, dim3(n), dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
                 st = check_launch("regress_kernel");

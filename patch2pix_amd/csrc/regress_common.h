@@ -1,6 +1,7 @@
-// Pieces shared by the two fine-stage kernels (exact-f32 MFMA and split-bf16 MFMA).
+// Pieces shared by the fine-stage kernels (exact-f32 MFMA, regress.hip; fp16x2, regress_h2.hip / regress_wino.hip).
 #pragma once
 #include "p2p_common.h"
+#include <algorithm>
 #include <cstring>
 
 namespace p2p {
@@ -10,12 +11,12 @@ constexpr int MAXB = 16;                // image pairs per launch
 
 struct RegDev {
     const float *wp1, *wp2;             // f32 MFMA-fragment order (regress.hip)
-    const float *ws1, *ws2;             // split-bf16 fragment order (regress_split.hip), viewed as 16-byte units
     const float *wh1, *wh2;             // two-plane fp16 fragment order, per-channel power-of-two scales (regress_h2.hip)
     const float *bn1s, *bn1b, *bn2s, *bn2b;
     const float *bn1s_h, *bn2s_h;       // BN scales with the fp16 operand scales of regress_h2.hip folded in
     const float *fc1t, *fc1b, *bnf1s, *bnf1b, *fc2t, *fc2b, *bnf2s, *bnf2b, *fc3, *fc3b;
     const float *fc1p, *fc2p;           // fc1 / fc2 in v_mfma_f32_16x16x4_f32 fragment order (fc_batch_parse)
+    const float *ww2, *bn2s_w;          // conv2 as Winograd-transformed filter blocks + its BN scale (regress_wino.hip)
 };
 
 struct ItemDev {
@@ -34,12 +35,28 @@ struct RegressArgs {
     RegDev reg[2];
     float *matches[2], *probs[2], *raw[2];
     float *ws;                    // regress_ws_floats(n) floats of scratch (kernels with the batched FC tail; else unused)
+    // P2P_REGRESS_FP16X2W only (regress_h2_kernel<true>): the level and proposal range of this launch, the transformed
+    // conv2 input it writes, the per-proposal inverse scales, the row blocks of the range
+    unsigned char *wU;
+    float *hinv;
+    int lvl0, p0, p1, mblocks;
 };
 
 // scratch of the kernels whose FC tail is batched over a work-group's proposals (regress_h2.hip): the pooled
 // convolution features V [level][n][512] and the un-truncated mid matches [n][4] the fine level starts from
 constexpr int FC_ROWS = 16;             // proposals per FC batch = rows of a v_mfma_f32_16x16x4_f32 tile
-static inline size_t regress_ws_floats(size_t n) { return ((2 * n * 512 + 31) & ~size_t(31)) + 4 * n + 32; }
+// P2P_REGRESS_FP16X2W appends: the inverse H scale per proposal of a chunk, and the transformed conv2 input of a chunk of at
+// most WINO_CHUNK proposals (16 positions x 16 tiles x 512 channels x 2 fp16 planes = 512 KiB per proposal), as the A
+// blocks of wino_gemm_kernel: [position 16][row block of 8 proposals][K chunk 16][WINO_BLK bytes]
+constexpr int WINO_BLK = 16384;         // [plane 2][row 128][32 K] fp16
+constexpr int WINO_CHUNK = 2048;        // proposals per conv1 -> GEMM round (a whole number of rounds of both kernels on 256 CUs)
+static inline size_t regress_ws_base_floats(size_t n) { return ((2 * n * 512 + 31) & ~size_t(31)) + 4 * n + 32; }
+static inline size_t wino_hinv_offset_floats(size_t n) { return (regress_ws_base_floats(n) + 63) & ~size_t(63); }
+static inline size_t wino_chunk_rows(size_t n) { return (std::min(n, (size_t)WINO_CHUNK) + 7) & ~size_t(7); }
+static inline size_t wino_u_offset_floats(size_t n) { return (wino_hinv_offset_floats(n) + wino_chunk_rows(n) + 63) & ~size_t(63); }
+static inline size_t regress_ws_floats(size_t n) {
+    return wino_u_offset_floats(n) + (size_t)16 * (wino_chunk_rows(n) / 8) * 16 * (WINO_BLK / 4);
+}
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -287,18 +304,12 @@ static inline void pack_fc_mfma(const float *w, int N, float *out) {
                     out[(((size_t)S * (N / 16) + t) * 64 + lane) * 4 + j] = w[(size_t)(16 * t + (lane & 15)) * 512 + 16 * S + 4 * (lane >> 4) + j];
 }
 
-// regress_split.hip
+// regress_h2.hip: the K axis of the two convolutions in slabs of 16
 constexpr int S1_SLABS = 4 + 9 * 2 * 16; // conv1: 4 slabs of level 0 (3 ch x 9 taps x 2 images, padded 54 -> 64), then per
                                         // (tap, image) 4 + 4 + 8 slabs of 16 channels of levels 1, 2, 3
 constexpr int S2_SLABS = 9 * 32;        // conv2: 512 channels / 16 per tap
-constexpr int SPF = 7;                  // weight prefetch distance in units = ring of 8 register buffers
 constexpr int S1_UNITS = 2 * S1_SLABS;   // conv1 streams one n-tile at a time: unit = (slab, n-tile), 2 KiB per (wave, unit)
-constexpr size_t WS1_FLOATS = (size_t)8 * (S1_UNITS + SPF) * 512;
 constexpr int S2_UNITS = 2 * S2_SLABS;   // conv2 likewise: [tap][n-tile][32 slabs]
-constexpr size_t WS2_FLOATS = (size_t)8 * (S2_UNITS + SPF) * 512;
-void pack_split_weights(const float *conv1_w, const float *conv2_w, float *ws1, float *ws2);   // host
-int launch_regress_split(const RegressArgs &a, int n, hipStream_t stream);
-void split_conv1_index(int slab, int half, int j, int &ch, int &tap);   // K layout of conv1 shared by the bf16 kernels
 
 // regress_h2.hip: unit = (slab of 16 K, n-tile), two fp16 planes = 2 KiB per (wave, unit); stream order [slab][n-tile]
 constexpr int XPF = 8;                   // units the weight prefetch may run past the end of a stream
@@ -307,19 +318,11 @@ constexpr size_t WH1_FLOATS = (size_t)8 * (S1_UNITS + XPF) * 512;
 constexpr size_t WH2_FLOATS = (size_t)8 * (S2_UNITS + XPF) * 512;
 void pack_h2_weights(const float *conv1_w, const float *conv2_w, float *wh1, float *wh2, int *t1, int *t2);      // host
 int launch_regress_h2(const RegressArgs &a, int n, hipStream_t stream);
+int launch_regress_h2_conv1(const RegressArgs &a, int n, hipStream_t stream);   // conv1 -> transformed conv2 input (FP16X2W)
 
-// host-side bf16 helpers (round to nearest even)
-static inline uint16_t bf16_rne(float f) {
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-static inline float bf16_to_f(uint16_t b) {
-    uint32_t u = (uint32_t)b << 16;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
+// regress_wino.hip: conv2 as Winograd F(2x2, 3x3) GEMMs; filter blocks [position 16][column block 4][K chunk 16][WINO_BLK]
+constexpr size_t WW2_FLOATS = (size_t)16 * 4 * 16 * (WINO_BLK / 4);
+void pack_wino_weights(const float *conv2_w, float *ww2, int *t2);                // host
+int launch_regress_wino(RegressArgs a, int n, hipStream_t stream);
 
 }  // namespace p2p

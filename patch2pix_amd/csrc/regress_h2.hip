@@ -355,6 +355,10 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // proposals g, g + G, g + 2G, ...  Per level it runs the two convolutions of each of its proposals (pooled features V[512]
 // -> global scratch), then the FC tail of ALL of them as one batch (fc_batch_parse: weights streamed once per 16
 // proposals), whose regressed matches are the next level's proposals (patch2pix.py:259-272).
+// WINO (arithmetic P2P_REGRESS_FP16X2W, regress_wino.hip): the launch covers ONE level (args.lvl0) and the proposals
+// [args.p0, args.p1); a work-group runs conv1 only and leaves the Winograd-transformed input of conv2 (B^T d B of every
+// 2 x 2 output tile, two fp16 planes) in the global buffer wino_gemm_kernel reads; conv2 and the FC tail are other launches.
+template <bool WINO>
 __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
     P2P_DYN_SHARED(unsigned char, smb);
     const int tid = threadIdx.x;
@@ -370,10 +374,10 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
 #define XWS_NEXTP() (args.ws + ((2 * (size_t)args.n * 512 + 31) & ~(size_t)31))
 
 #pragma unroll 1
-    for (int lvl = 0; lvl < args.nlevels; ++lvl) {
+    for (int lvl = WINO ? args.lvl0 : 0; lvl < (WINO ? args.lvl0 + 1 : args.nlevels); ++lvl) {
         const RegDev &R_ = args.reg[lvl];
 #pragma unroll 1
-      for (int prop = blockIdx.x; prop < args.n; prop += nwg) {
+      for (int prop = (WINO ? args.p0 : 0) + blockIdx.x; prop < (WINO ? args.p1 : args.n); prop += nwg) {
         int it = 0;
         while (it + 1 < args.nitems && prop >= args.start[it + 1]) ++it;
         if (args.dev_counts && prop - args.start[it] >= args.dev_counts[it]) continue;      // empty slot (whole work-group)
@@ -744,6 +748,96 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
         __syncthreads();   // all waves are done reading the conv1 operands
         XT(7)
 
+        if constexpr (WINO) {
+            // BN1 -> H (fp32, scaled per proposal) -> LDS [pixel 64 + one row of zeros][512 ch (+16 B)] -> B^T d B of the 16
+            // tiles (4 x 4 windows at stride 2 over the zero-padded 8 x 8 map) -> two fp16 planes -> the A blocks of
+            // wino_gemm_kernel: [position 16][row block][K chunk 16][plane 2][row 128][4 pieces of 8 ch, XOR-swizzled].
+            constexpr int HWST = 512 * 4 + 16;
+            static_assert(65 * HWST <= XSM_MISC, "H as fp32 fits the convolution buffers");
+            {
+                float mx = 0.f;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int n = wave * 64 + u * 32 + l31;
+                    const float s = R_.bn1s_h[n], b = R_.bn1b[n];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const f32x16 &a = (t == 0) ? (u == 0 ? acc00 : acc01) : (u == 0 ? acc10 : acc11);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(fmaf(a[r], s, b)));
+                    }
+                }
+                atomicMax((int *)misc + 14, __float_as_int(mx));
+            }
+            if (tidv < HWST / 16) {
+                float zf = 0.f;
+                P2P_OPAQUE(zf);
+                *(f32x4 *)(smb + 64 * HWST + tidv * 16) = (f32x4){zf, zf, zf, zf};
+            }
+            __syncthreads();
+            // |H| * hmul in [2^10, 2^11): the transform grows a value at most fourfold, |U| < 2^13
+            const int eb = clampi((((const int *)misc)[14] >> 23) & 0xff, 20, 250);
+            const float hmul = __int_as_float((264 - eb) << 23);
+            if (tidv == 0) args.hinv[prop - args.p0] = __int_as_float((eb - 10) << 23);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n = wave * 64 + u * 32 + l31;
+                const float s = R_.bn1s_h[n], b = R_.bn1b[n];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const f32x16 &a = (t == 0) ? (u == 0 ? acc00 : acc01) : (u == 0 ? acc10 : acc11);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int p = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        *(float *)(smb + p * HWST + n * 4) = fmaf(a[r], s, b) * hmul;
+                    }
+                }
+            }
+            __syncthreads();
+            // item = (half of the tiles, K chunk of 32 channels): lane = (tile of the half, 4 channels); 4 items per wave
+            const int lq = tidv & 63, cq = lq & 7;
+            const unsigned pl = (unsigned)(prop - args.p0);
+            const unsigned pstride = (unsigned)args.mblocks * (16u * WINO_BLK);
+#pragma unroll 1
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const int item = wave * 4 + i4, kc = item & 15;
+                const int tile = 8 * (item >> 4) + (lq >> 3), ty = tile >> 2, tx = tile & 3;
+                f32x4 d[4][4];
+#pragma unroll
+                for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+                    for (int bb = 0; bb < 4; ++bb) {
+                        const int y = 2 * ty + aa - 1, x = 2 * tx + bb - 1;
+                        const int px = ((unsigned)y < 8u && (unsigned)x < 8u) ? y * 8 + x : 64;
+                        d[aa][bb] = *(const f32x4 *)(smb + px * HWST + (kc * 32 + cq * 4) * 4);
+                    }
+                // B^T d B,  B^T = [[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]]
+                f32x4 tr[4][4];
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    tr[0][bb] = d[0][bb] - d[2][bb];
+                    tr[1][bb] = d[1][bb] + d[2][bb];
+                    tr[2][bb] = d[2][bb] - d[1][bb];
+                    tr[3][bb] = d[1][bb] - d[3][bb];
+                }
+                const unsigned rr = (pl & 7u) * 16u + (unsigned)tile;
+                const unsigned inblk = (rr * 4u + (((unsigned)cq >> 1) ^ ((rr >> 2) & 3u))) * 16u + ((unsigned)cq & 1u) * 8u;
+                unsigned char *ub = args.wU + (size_t)(((pl >> 3) * 16u + (unsigned)kc) * (unsigned)WINO_BLK + inblk);
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const f32x4 v = (jj == 0) ? tr[ii][0] - tr[ii][2] : (jj == 1) ? tr[ii][1] + tr[ii][2]
+                                      : (jj == 2) ? tr[ii][2] - tr[ii][1] : tr[ii][1] - tr[ii][3];
+                        const unsigned h0a = pk_e(v[0], v[1]), h0b = pk_e(v[2], v[3]);
+                        const unsigned h1a = pk_e(v[0] - pk_lo(h0a), v[1] - pk_hi(h0a));
+                        const unsigned h1b = pk_e(v[2] - pk_lo(h0b), v[3] - pk_hi(h0b));
+                        unsigned char *dst = ub + (size_t)(ii * 4 + jj) * pstride;
+                        *(uint2 *)dst = make_uint2(h0a, h0b);
+                        *(uint2 *)(dst + WINO_BLK / 2) = make_uint2(h1a, h1b);
+                    }
+            }
+        } else {
         // BN1 -> H.  Two planes: every wave writes the planes of its 64 channels into its chunk (wave >> 1).  Three planes:
         // chunk 0 (channels of waves 0, 1) as planes, the other chunks wait as fp32
         {
@@ -884,6 +978,7 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                 if (half == 0) XWS_V(lvl)[(size_t)prop * 512 + n] = m;       // pooled features: the FC batch of the level reads them back
             }
         }
+        }
         __syncthreads();       // every wave is done with the proposal's LDS (the next gather overwrites it)
         XT(11)
 #ifdef P2P_X3_TIMING
@@ -898,6 +993,7 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
       }
         // ------------------------------------------------------------ FC tail of all this work-group's proposals
         __builtin_amdgcn_s_setprio(0);
+        if constexpr (!WINO) {
         __threadfence();       // the V rows written above are visible to the (cache-bypassing) loads of the batch
         __syncthreads();
 #ifndef XF_SKIP_FC                      // timing experiment (wrong results)
@@ -905,6 +1001,7 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
 #endif
         __threadfence();       // ... and the regressed matches to the next level's proposal loads
         __syncthreads();
+        }
     }
 }
 
@@ -914,6 +1011,23 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
 // conv2: [chunk of 128 input channels][tap][8 slabs][n-tile].  A unit is [plane 2][lane 64][8 fp16]; K of a conv1
 // slab as in split_conv1_index.
 // --------------------------------------------------------------------------------------------------
+// K layout of conv1: slab (16 K) -> (input channel of cat(f1, f2), tap) of the value lane half `half`, element j holds.
+// Slabs 0-3 = level 0 of both images (K = img * 32 + tap * 3 + c, 27 real per image), then per (tap, image) 16 slabs:
+// 4 of level 1 (64 ch), 4 of level 2 (64 ch), 8 of level 3 (128 ch).
+static void split_conv1_index(int slab, int half, int j, int &ch, int &tap) {
+    if (slab < 4) {
+        const int kk = slab * 16 + 8 * half + j, img = kk >> 5, r = kk & 31;
+        if (r >= 27) { ch = -1; tap = 0; return; }
+        tap = r / 3;
+        ch = img * 259 + (r % 3);
+        return;
+    }
+    const int q = slab - 4, s = q % 16, img = (q / 16) % 2;
+    tap = q / 32;
+    const int base = (s < 4) ? 3 + s * 16 : (s < 8) ? 67 + (s - 4) * 16 : 131 + (s - 8) * 16;
+    ch = img * 259 + base + 8 * half + j;
+}
+
 static uint16_t host_e(float v) {
     return __builtin_bit_cast(uint16_t, (_Float16)v);
 }
@@ -1008,13 +1122,15 @@ void pack_h2_weights(const float *conv1_w, const float *conv2_w, float *wx1, flo
         }
 }
 
-int launch_regress_h2(const RegressArgs &a, int n, hipStream_t stream) {
+static int launch_h2(const RegressArgs &a, int n, bool wino, hipStream_t stream) {
     int dev = 0;
     P2P_HIP_CHECK(hipGetDevice(&dev));
     static bool attr_set[64] = {false};
     static int cus[64] = {0};
     if (dev >= 64 || !attr_set[dev]) {
-        P2P_HIP_CHECK(hipFuncSetAttribute((const void *)regress_h2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        P2P_HIP_CHECK(hipFuncSetAttribute((const void *)regress_h2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)XSM_BYTES));
+        P2P_HIP_CHECK(hipFuncSetAttribute((const void *)regress_h2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)XSM_BYTES));
         int ncu = 0;
         P2P_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -1028,8 +1144,13 @@ int launch_regress_h2(const RegressArgs &a, int n, hipStream_t stream) {
     const int ncu = cus[dev < 64 ? dev : 0];
 #endif
     P2P_REQUIRE(a.ws, P2P_EINVAL, "%s: the scratch buffer is missing", "regress_h2_kernel");
-    hipLaunchKernelGGL(regress_h2_kernel, dim3(std::min(n, std::max(ncu, 1))), dim3(NT), XSM_BYTES, stream, a);
+    if (wino) hipLaunchKernelGGL(regress_h2_kernel<true>, dim3(std::min(n, std::max(ncu, 1))), dim3(NT), XSM_BYTES, stream, a);
+    else hipLaunchKernelGGL(regress_h2_kernel<false>, dim3(std::min(n, std::max(ncu, 1))), dim3(NT), XSM_BYTES, stream, a);
     return check_launch("regress_h2_kernel");
 }
+
+int launch_regress_h2(const RegressArgs &a, int n, hipStream_t stream) { return launch_h2(a, n, false, stream); }
+// conv1 of the proposals [a.p0, a.p1) of level a.lvl0 -> the transformed conv2 input (regress_wino.hip); n = a.p1 - a.p0
+int launch_regress_h2_conv1(const RegressArgs &a, int n, hipStream_t stream) { return launch_h2(a, n, true, stream); }
 
 }  // namespace p2p

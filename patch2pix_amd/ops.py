@@ -183,7 +183,7 @@ class RegressorWeights:
 
     def set_mode(self, mode):
         """'fp16x2' (default: fp32-equivalent, two fp16 planes under exact power-of-two scales, 3 MFMA products), 'f32'
-        (exact fp32 MFMA) or 'bf16x2' (reduced precision, 16 significant bits; opt-in).  The first selection of a
+        (exact fp32 MFMA) or 'fp16x2w' (fp16x2 with the second convolution as Winograd F(2x2,3x3) GEMMs).  The first selection of a
         non-default mode packs and uploads that mode's weight stream (host work, ~1 s)."""
         if mode not in _lib.REGRESS_MODES:
             raise ValueError(f"unknown regressor mode {mode!r}: one of {sorted(_lib.REGRESS_MODES)}")

@@ -78,7 +78,7 @@ def coarse_matches_batch(emu, corr, delta, ksize, upsample, center=True):
 
 
 def regressor_create(emu, sd, mode):
-    """sd: sub-state_dict of one FeatRegressNet ('conv.0.weight', ...); mode 'f32' | 'bf16x2'."""
+    """sd: sub-state_dict of one FeatRegressNet ('conv.0.weight', ...); mode 'f32' | 'fp16x2'."""
     keep = {k: v.detach().float().contiguous() for k, v in sd.items() if v.is_floating_point()}
     p = real.RegressorParams()
 

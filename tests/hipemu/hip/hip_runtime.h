@@ -32,11 +32,19 @@
 #define P2P_LANE_ID() ((int)(hipemu::ctx().thread.x & 63))
 #define P2P_DYN_SHARED(T, name) T *name = (T *)hipemu::dynamic_shared()
 #define P2P_WAVE_SYNC() do { char z_ = 0; (void)hipemu::wave_gather(&z_, 1); } while (0)   /* the lanes are fibers: rendezvous */
+// LDS-DMA (global_load_lds_dwordx4): the copy happens at once -- a kernel that is correct for ANY completion time before its
+// counted wait is correct for this one; what the stand-in cannot see is a wait that is missing or counts wrongly
+#define P2P_GLOBAL_LOAD_LDS16(gptr, lptr, imm) \
+    memcpy((unsigned char *)(lptr) + (imm) + 16 * P2P_LANE_ID(), (const unsigned char *)(gptr) + (imm), 16)
+#define P2P_WAIT_VMCNT(n) ((void)0)
 
 struct dim3 {
     unsigned x, y, z;
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
+
+struct uint2 { unsigned x, y; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 
 namespace hipemu {
 struct Idx { unsigned x, y, z; };

@@ -34,7 +34,7 @@ def ops():
     return ops
 
 
-MODES = ["fp16x2", "f32", "bf16x2"]   # fp32-equivalent on two fp16 planes (the default), exact fp32 MFMA, reduced precision (opt-in)
+MODES = ["fp16x2", "fp16x2w", "f32"]   # fp32-equivalent on two fp16 planes (direct conv2 | Winograd conv2), exact fp32 MFMA
 DEFAULT_MODE = "fp16x2"                         # include/p2p_hip.h: P2P_REGRESS_DEFAULT
 
 

@@ -90,7 +90,7 @@ def test_coarse_batch_equals_single_pairs(emu, ncn):
             assert torch.equal(m[i], m1[0]) and torch.equal(s[i], s1[0])
 
 
-@pytest.mark.parametrize("mode", ["fp16x2", "bf16x2", "f32"])
+@pytest.mark.parametrize("mode", ["fp16x2", "f32"])
 def test_regressors_against_reference_golden(mode, emu, sd):
     """Both regressor kernels (split-bf16 and exact fp32 MFMA) on the first proposals of the reference's
     forward_fine_match golden: integer proposals through the mid regressor, float proposals through the fine one."""
@@ -138,7 +138,7 @@ torch.save((props, out), sys.argv[1])
     assert (out["matches1"] - ref_mid).abs().max() <= COORD_TOL and (out["probs1"] - ref_midp).abs().max() <= SCORE_TOL
 
 
-@pytest.mark.parametrize("mode", ["fp16x2", "bf16x2"])
+@pytest.mark.parametrize("mode", ["fp16x2"])
 def test_regressor_chain_and_image_borders(mode, emu, sd):
     """Mid -> fine inside one launch (the fine patch is centred on the truncated mid match, its base is the
     un-truncated one), with proposals on the image corners where every level of the patch clamps."""
@@ -161,7 +161,7 @@ def test_regressor_chain_and_image_borders(mode, emu, sd):
     assert (out["probs2"] - ref_finep).abs().max() <= SCORE_TOL
 
 
-@pytest.mark.parametrize("mode", ["fp16x2", "bf16x2"])
+@pytest.mark.parametrize("mode", ["fp16x2"])
 def test_regress_batch_items_of_different_sizes(mode, emu, sd):
     """p2p_regress_batch over items (pairs) of different image sizes, one of them empty == one call per item."""
     import ctypes
@@ -320,7 +320,7 @@ def test_device_filter_coarse_long_lists(n, distinct, emu):
     assert torch.equal(got[0][0], r) and torch.equal(got[0][1], rs)
 
 
-@pytest.mark.parametrize("mode", ["fp16x2", "bf16x2"])
+@pytest.mark.parametrize("mode", ["fp16x2"])
 def test_regress_with_device_counts(mode, emu, sd):
     """p2p_regress_batch_dev: every item owns `stride` slots, the first counts[i] hold proposals; used slots equal the
     per-item call bit for bit, the others are not touched."""

@@ -18,7 +18,7 @@ for spec in "$@"; do
     [ "$spec" != "$name" ] && flags=$(echo "${spec#*=}" | tr ',' ' ')
     tmp=$(mktemp -d)
     objs=""
-    for f in api backbone coarse consensus filter regress regress_split regress_h2; do
+    for f in api backbone coarse consensus filter regress regress_h2; do
         /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c "$ROOT/patch2pix_amd/csrc/$f.hip" -o "$tmp/$f.o" -Rpass-analysis=kernel-resource-usage 2>&1 | grep -A7 "regress_h2_kernel" | grep -E "VGPRs:|ScratchSize" || true
         objs="$objs $tmp/$f.o"
     done
