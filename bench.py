@@ -52,6 +52,13 @@ FLOP_PER_PROPOSAL_LEVEL = 2 * 64 * 512 * (518 * 9) + 2 * 64 * 512 * (512 * 9) + 
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 MODES = {
+    "fp16x2w": dict(kernel="p2p_regress_batch", products=3, peak=PEAK_BF16_MFMA_TFLOPS / 3.0,
+                    kernels=["regress_h2_kernel<true>", "wino_gemm_kernel", "regress_fc_kernel"],
+                    dtype="f32-equivalent: fp16x2 (every f32 operand, scaled by an exact power of two, = sum of 2 fp16 planes to within "
+                          "2^-24 of its magnitude; 3 fp16 MFMA products per f32 product, f32 accumulate); second convolution as "
+                          "Winograd F(2x2,3x3) (transforms in f32, filters transformed in f64)",
+                    peak_note="peak = 2500 TFLOP/s dense fp16 MFMA / 3 MFMA products per fp32 product; the flop count is the "
+                              "DIRECT convolutions' (608.3 MFLOP per proposal and level) although conv2 issues 2.25x fewer"),
     "fp16x2": dict(kernel="regress_h2_kernel", products=3, peak=PEAK_BF16_MFMA_TFLOPS / 3.0,
                    dtype="f32-equivalent: fp16x2 (every f32 operand, scaled by an exact power of two, = sum of 2 fp16 planes to within "
                          "2^-24 of its magnitude; 3 fp16 MFMA products per f32 product, f32 accumulate)",
@@ -272,11 +279,19 @@ def roofline_of(mode, events):
     # achieved = ALGORITHMIC flop of one regress launch (608.3 MFLOP per proposal and level) / its
     # average duration (HIP events on the launch stream)
     achieved = flop / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-    return {"kernel": M["kernel"], "bound": "mfma", "achieved": achieved, "peak": M["peak"], "unit": "TFLOP/s",
-            "frac": achieved / M["peak"], "traffic": None, "avg_launch_ms": avg_ms, "algorithmic_flop_per_launch": flop,
-            "peak_note": M["peak_note"],
-            "note": "achieved = algorithmic flop of the launch (608.3 MFLOP x proposals x levels) / launch time "
-                    "measured with HIP events on the launch stream"}
+    out = {"kernel": M["kernel"], "bound": "mfma", "achieved": achieved, "peak": M["peak"], "unit": "TFLOP/s",
+           "frac": achieved / M["peak"], "traffic": None, "avg_launch_ms": avg_ms, "algorithmic_flop_per_launch": flop,
+           "peak_note": M["peak_note"],
+           "note": "achieved = algorithmic flop of the launch (608.3 MFLOP x proposals x levels) / launch time "
+                   "measured with HIP events on the launch stream"}
+    if "kernels" in M:
+        out["kernels"] = M["kernels"]
+        out["note"] = ("the fine stage of one step = ONE p2p_regress_batch call = per regressor level and chunk of 2048 proposals "
+                       "regress_h2_kernel<true> (gather + conv1 -> transformed conv2 input) and wino_gemm_kernel (conv2 as 16 "
+                       "batched GEMMs + BN + max-pool), then regress_fc_kernel per level; achieved = algorithmic flop of the call "
+                       "(608.3 MFLOP x proposals x levels) / its duration between HIP events on the launch stream = the sum of "
+                       "its kernels in the rocprofv3 summary")
+    return out
 
 
 def add_traffic(roof, mode, config, proposals_per_launch):
@@ -286,15 +301,18 @@ def add_traffic(roof, mode, config, proposals_per_launch):
     if not os.path.exists(tf):
         return
     rec = json.load(open(tf)).get(mode if config == "A" else f"{mode}@{config}", {})
-    if (rec.get("kernel") == MODES[mode]["kernel"] and rec.get("proposals_per_launch") == proposals_per_launch
+    if (rec.get("kernel") == "+".join(MODES[mode].get("kernels", [MODES[mode]["kernel"]])) and rec.get("proposals_per_launch") == proposals_per_launch
             and rec.get("config", "A") == config and rec.get("source_hash") == source_hash()):
         roof["traffic"] = rec.get("hbm_bytes_per_launch")
         roof["traffic_source"] = rec.get("source")
-        roof["traffic_note"] = ("FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE of the kernel per launch = requests on the "
+        roof["traffic_note"] = ("FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE of the call's kernels = requests on the "
                                 "L2's fabric side: Infinity-Cache hits are included, so this is an upper bound of the HBM "
-                                "bytes; the compulsory bytes of a 16-pair launch are ~1 GB (16 x 61 MB of pyramids + 57 MB of "
-                                "weights), the rest are L2 capacity misses of the 28.5 MB-per-level weight stream, which "
-                                "lives in the 256 MB Infinity Cache")
+                                "bytes; the compulsory bytes of a 16-pair launch are ~1 GB (16 x 61 MB of pyramids + 70 MB of "
+                                "weights) -- plus, in the Winograd mode, the transformed conv2 input written once and read once "
+                                "(512 KiB per proposal and level); the rest are L2 capacity misses of the conv1 weight stream, "
+                                "which lives in the 256 MB Infinity Cache")
+        if rec.get("per_kernel"):
+            roof["traffic_per_kernel"] = rec["per_kernel"]
 
 
 class Runner:

@@ -47,7 +47,7 @@ const char *p2p_last_error(void);
 int p2p_ncn_create(const float *w1, const float *b1, const float *w2, const float *b2, p2p_ncn **out);
 void p2p_ncn_destroy(p2p_ncn *ncn);
 /* Tests and sweeps: force the work-group tile (ta, tb, tc) of the consensus kernel for launches with this handle (0, 0, 0 =
- * automatic; ta = 0 with tb, tc > 0: only the march length is picked).  Results do not depend on the tile: every output
+ * automatic; ta = 0 with tb, tc > 0: only the march length is picked; any other partial triple is P2P_EINVAL).  Results do not depend on the tile: every output
  * cell sums its contributions in one fixed order.                                                                   */
 int p2p_ncn_set_tile(p2p_ncn *ncn, int ta, int tb, int tc);
 
@@ -75,13 +75,13 @@ void p2p_regressor_destroy(p2p_regressor *reg);
 
 /* Arithmetic used for the two convolutions of a regressor (everything else is fp32 either way; the
  * reference computes them in fp32, networks/modules.py:76-87):
- *   P2P_REGRESS_FP16X2 (default) fp32-equivalent on the fp16 matrix cores: every fp32 operand, scaled by an exact power of
+ *   P2P_REGRESS_FP16X2 fp32-equivalent on the fp16 matrix cores: every fp32 operand, scaled by an exact power of
  *                      two into the normal range of fp16, is the sum of two fp16 numbers to within 2^-24 of its
  *                      magnitude; three v_mfma_f32_32x32x16_f16 per product (the dropped term is <= 2^-24 of it),
  *                      fp32 accumulation; the scales are undone exactly.  As accurate as P2P_REGRESS_F32 against
  *                      an fp64 evaluation at 5.3x its matrix-core ceiling;
  *   P2P_REGRESS_F32    v_mfma_f32_32x32x2_f32, bit-identical to an fp32 fma chain;
- *   P2P_REGRESS_FP16X2W the same arithmetic with the second convolution (3x3, stride 1 on the 8x8 map) evaluated as
+ *   P2P_REGRESS_FP16X2W (default) the same arithmetic with the second convolution (3x3, stride 1 on the 8x8 map) evaluated as
  *                      Winograd F(2x2, 3x3): 16 batched GEMMs over the transformed tiles of ALL proposals (2.25x fewer
  *                      matrix-core passes; the transforms are exact up to fp32 rounding, transformed filters computed in
  *                      fp64 at pack time) -- three launches per regressor level instead of one, and a larger scratch
@@ -92,7 +92,7 @@ void p2p_regressor_destroy(p2p_regressor *reg);
 #define P2P_REGRESS_F32     0
 #define P2P_REGRESS_FP16X2  3
 #define P2P_REGRESS_FP16X2W 4
-#define P2P_REGRESS_DEFAULT P2P_REGRESS_FP16X2
+#define P2P_REGRESS_DEFAULT P2P_REGRESS_FP16X2W
 int p2p_regressor_set_mode(p2p_regressor *reg, int mode);
 int p2p_regressor_get_mode(const p2p_regressor *reg);
 

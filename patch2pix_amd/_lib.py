@@ -9,7 +9,15 @@ import os
 import torch  # noqa: F401  (must be loaded first so libamdhip64.so.7 resolves to torch's copy)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("P2P_LIB_PATH", os.path.join(_HERE, "csrc", "libp2p_hip.so"))   # override: kernel experiments
+LIB_PATH = os.path.join(_HERE, "csrc", "libp2p_hip.so")
+# Kernel experiments (tools/ab_variants.sh) load another build through P2P_LIB_PATH -- only together with
+# P2P_ALLOW_EXPERIMENT=1, so that a stray variable in a user's environment can never swap the library.
+_ALLOW_EXPERIMENT = os.environ.get("P2P_ALLOW_EXPERIMENT") == "1"
+if os.environ.get("P2P_LIB_PATH"):
+    if not _ALLOW_EXPERIMENT:
+        raise ImportError("P2P_LIB_PATH is set but P2P_ALLOW_EXPERIMENT=1 is not: refusing to load a library other than "
+                          f"{LIB_PATH}")
+    LIB_PATH = os.environ["P2P_LIB_PATH"]
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -47,6 +55,9 @@ def _sig(name, restype, argtypes):
 
 
 p2p_version = _sig("p2p_version", ctypes.c_int, [])
+VERSION_EXPERIMENT = 0x40000000     # csrc/p2p_common.h: a build with timing-experiment switches (wrong results by design)
+if p2p_version() & VERSION_EXPERIMENT and not _ALLOW_EXPERIMENT:
+    raise ImportError(f"{LIB_PATH} is an experiment build (-DP2P_EXPERIMENT); set P2P_ALLOW_EXPERIMENT=1 to load it")
 p2p_last_error = _sig("p2p_last_error", ctypes.c_char_p, [])
 p2p_ncn_create = _sig("p2p_ncn_create", ctypes.c_int,
                       [ctypes.c_void_p] * 4 + [ctypes.POINTER(ctypes.c_void_p)])

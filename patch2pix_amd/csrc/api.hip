@@ -11,5 +11,9 @@ void set_error(const char *fmt, ...) {
 }
 }  // namespace p2p
 
-extern "C" int p2p_version(void) { return 101; }
+#ifdef P2P_EXPERIMENT
+extern "C" int p2p_version(void) { return 102 | P2P_VERSION_EXPERIMENT; }
+#else
+extern "C" int p2p_version(void) { return 102; }
+#endif
 extern "C" const char *p2p_last_error(void) { return p2p::g_err; }

@@ -3,9 +3,11 @@
 // consensus (two 3^4 convolutions, symmetric) -> mutual matching -> soft mutual-NN matches.
 //
 // Data layout in HBM (A = image 1 cells, B = image 2 cells):
-//   Fn      [plane 2][pos'][C] fp16: L2-normalised layer-3 features x 2^12 as two fp16 planes, position-major
-//                         (K contiguous) and with positions re-ordered cell-major so that the k^2 positions of
-//                         one pooling cell are adjacent: pos' = cell*k^2 + (i%k)*k + (j%k)
+//   Fn      [row block of 128 pos'][K chunk of 32 ch][plane 2][row 128][4 pieces of 8 ch] fp16: L2-normalised layer-3
+//                         features x 2^12 as two fp16 planes, in the 16 KB blocks the correlation GEMM copies into LDS by
+//                         LDS-DMA (piece q of row r at slot q ^ ((r >> 2) & 3): conflict-free fragment reads); positions
+//                         re-ordered cell-major so that the k^2 positions of one pooling cell are adjacent:
+//                         pos' = cell*k^2 + (i%k)*k + (j%k)
 //   P, Y, Y2 [nA'][nB']   fp32 pooled correlation volume viewed as a matrix (row = A cell, col = B cell); Y / Y2 =
 //                         the two branches of the consensus net (consensus.hip), summed by the kernels that read them
 //   delta   [nA'][nB']    uint8 argmax code s = ((di*k+dj)*k+dk)*k+dl
@@ -41,8 +43,8 @@ constexpr int KEY_NEG_INF = (int)0xff800000 ^ 0x7fffffff;
 // 1. L2 normalise + transpose to position-major with cell-major position order (modules.py:6)
 // ------------------------------------------------------------------------------------------------
 constexpr int PREP_P = 16;    // positions per work-group (300 groups at 60x80: fills the chip)
-// Writes the normalised features x 2^12 as two fp16 planes [plane][pos'][C] (|v| <= 1, so both planes stay in the normal
-// range of fp16 and v * 2^12 = p0 + p1 to within 2^-24 |v * 2^12|).  The plane stride is hw * C elements.
+// Writes the normalised features x 2^12 as two fp16 planes (|v| <= 1, so both planes stay in the normal range of fp16 and
+// v * 2^12 = p0 + p1 to within 2^-24 |v * 2^12|) in the block layout of the correlation GEMM (CX_BLK, below).
 constexpr float CORR_FP16_SCALE = 4096.0f;
 // One launch for both images of every pair (blockIdx.y = image); the same launch resets the maxima keys of the mutual
 // matchings (nkeys words = -inf, then one word = 0: the float bits of max |X|, see mm_apply_kernel).
@@ -107,10 +109,13 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
         const int pp = ((i / k) * wc + (j / k)) * (k * k) + (i % k) * k + (j % k);
         for (int c = tid; c < C; c += 256) {
             const float x = tile[c * (PREP_P + 1) + p] * inv[p] * CORR_FP16_SCALE;
-            unsigned short *d = Fn + (size_t)pp * C + c;
+            // block (pp / 128, c / 32): [plane][row pp % 128][piece (c / 8) % 4 at slot piece ^ ((row / 4) % 4)][c % 8]
+            const int r = pp & 127;
+            unsigned short *d = Fn + ((size_t)(pp >> 7) * (C >> 5) + (c >> 5)) * (2 * 128 * 32) +
+                                (r * 4 + (((c >> 3) & 3) ^ ((r >> 2) & 3))) * 8 + (c & 7);
             const _Float16 h0 = (_Float16)x;
             d[0] = __builtin_bit_cast(unsigned short, h0);
-            d[(size_t)hw * C] = __builtin_bit_cast(unsigned short, (_Float16)(x - (float)h0));
+            d[128 * 32] = __builtin_bit_cast(unsigned short, (_Float16)(x - (float)h0));
         }
     }
 }
@@ -122,9 +127,12 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
 // fp32-equivalent arithmetic on the fp16 matrix cores: both operands arrive as two fp16 planes of the features times 2^12
 // (prep_kernel), three v_mfma_f32_32x32x16_f16 per product (a0 b0 + a0 b1 + a1 b0; the dropped a1 b1 is <= 2^-24 of the
 // product), the accumulators are scaled back by 2^-24 (exact) in the epilogue.  fp32 accumulation, no VALU in the loop: per
-// K = 16 slab and wave 8 ds_read_b128 and 12 MFMAs.  The K loop is double buffered: the global loads of stage i + 1 are in
-// flight while stage i is multiplied out of LDS, one barrier per stage.
-// LDS: [stage 2][A|B][plane 2][128 rows][32 K fp16 (+16 B pad)] = 80 KB.
+// K = 16 slab and wave 8 ds_read_b128 and 12 MFMAs.
+// Staging (round 5): the operands of a K = 32 stage are two 16 KB blocks that prep_kernel wrote as the LDS image, copied by
+// LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write_b128 -- the store path of the register-staged version
+// took more LDS cycles than the fragment reads) into a double buffer: the DMA of stage i + 1 is in flight while stage i is
+// multiplied, one vmcnt(0) + raw s_barrier per stage; the fragments of slab s + 1 are read behind the MFMAs of slab s.
+// LDS: [stage 2][A|B][plane 2][128 rows][4 pieces of 16 B, XOR-swizzled] = 64 KB, two work-groups per compute unit.
 //
 // Tile order.  The hardware deals consecutive work-group ids to the 8 XCDs round-robin, and every XCD has its own 4 MB L2.
 // A row-major raster therefore makes every XCD stream ALL B panels for every row of tiles (960x1280: 3.1 GB fetched per
@@ -136,21 +144,54 @@ constexpr int CX_AB = 16;    // tile rows per L2-resident block of A panels (16 
                              // 960x1280: 16 rows fetch 224 MB per pair, 24 rows 246 MB, 28 rows 682 MB -- the streaming B
                              // panels and the output need the other half)
 typedef _Float16 cf16x8 __attribute__((ext_vector_type(8)));
-constexpr int CX_ROW = 32 * 2 + 16;          // bytes per LDS row: 80 = 5 x 16 (odd multiple of 16 B: the 16 lanes of every ds_read_b128
-                                             // service group -- rows {0-3,12-15,20-27} etc. -- land on 16 different 16-byte slots)
-constexpr int CX_PLANE = CT * CX_ROW;        // 10240
-constexpr int CX_MAT = 2 * CX_PLANE, CX_STAGE = 2 * CX_MAT, CX_LDS = 2 * CX_STAGE;
+constexpr int CX_BLK = 2 * CT * 64;          // one operand block of a stage: [plane 2][row 128][32 K fp16] = 16 KB
+constexpr int CX_STAGE = 2 * CX_BLK, CX_LDS = 2 * CX_STAGE;
 __device__ __forceinline__ f32x16 cx_mfma(const f32x4 &a, const f32x4 &b, const f32x16 &c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cf16x8, a), __builtin_bit_cast(cf16x8, b), c, 0, 0, 0);
 }
+// stage IT of the tile -> ring slot SLOT: wave w copies bytes [4096 w, 4096 w + 4096) of the A and of the B block
+#define CX_ISSUE(IT, SLOT)                                                                                             \
+    {                                                                                                                  \
+        const unsigned char *ga_ = Ab + (size_t)(IT) * CX_BLK + lane16;                                                \
+        const unsigned char *gb_ = Bb + (size_t)(IT) * CX_BLK + lane16;                                                \
+        unsigned char *la_ = cx + (SLOT) * CX_STAGE + wave * 4096;                                                     \
+        P2P_GLOBAL_LOAD_LDS16(ga_, la_, 0); P2P_GLOBAL_LOAD_LDS16(ga_, la_, 1024);                                     \
+        P2P_GLOBAL_LOAD_LDS16(ga_, la_, 2048); P2P_GLOBAL_LOAD_LDS16(ga_, la_, 3072);                                  \
+        P2P_GLOBAL_LOAD_LDS16(gb_, la_ + CX_BLK, 0); P2P_GLOBAL_LOAD_LDS16(gb_, la_ + CX_BLK, 1024);                   \
+        P2P_GLOBAL_LOAD_LDS16(gb_, la_ + CX_BLK, 2048); P2P_GLOBAL_LOAD_LDS16(gb_, la_ + CX_BLK, 3072);                \
+    }
+// fragments of slab S of ring slot SLOT: a[m-tile][plane], b[n-tile][plane]
+#define CX_READ(FA, FB, SLOT, S)                                                                                       \
+    {                                                                                                                  \
+        const unsigned char *pa_ = cx + (SLOT) * CX_STAGE + ((S) ? aoff1 : aoff0);                                     \
+        const unsigned char *pb_ = cx + (SLOT) * CX_STAGE + CX_BLK + ((S) ? boff1 : boff0);                            \
+        _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_)                                                               \
+            _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                                         \
+                FA[t_][q_] = *(const f32x4 *)(pa_ + t_ * 2048 + q_ * 8192);                                            \
+                FB[t_][q_] = *(const f32x4 *)(pb_ + t_ * 2048 + q_ * 8192);                                            \
+            }                                                                                                          \
+    }
+// smallest terms first (a1 b0, a0 b1, a0 b0); the four accumulators rotate
+#define CX_SLAB(FA, FB)                                                                                                \
+    _Pragma("unroll") for (int t_ = 0; t_ < 3; ++t_) {                                                                 \
+        const int pa_ = (t_ == 0) ? 1 : 0, pb_ = (t_ == 1) ? 1 : 0;                                                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                               \
+            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) acc[i_][j_] = cx_mfma(FA[i_][pa_], FB[j_][pb_], acc[i_][j_]); \
+    }
+// one LDS read behind each of the first eight MFMAs of a slab (left alone the compiler builds read -> wait -> MFMA chains)
+#define CX_PIPE()                                                                                                      \
+    _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }        \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_barrier(0);
 
 template <int KS>
-__global__ __launch_bounds__(256) void corr_pool_kernel(const unsigned short *__restrict__ A, const unsigned short *__restrict__ B,
-                                                        int nA, int nB, int C, float *__restrict__ P,
-                                                        uint8_t *__restrict__ delta, size_t sAB, size_t sP, size_t sDelta,
-                                                        int gx, int gy, int ntiles) {
+__global__ __launch_bounds__(256, 2) void corr_pool_kernel(const unsigned short *__restrict__ A, const unsigned short *__restrict__ B,
+                                                           int nA, int nB, int C, float *__restrict__ P,
+                                                           uint8_t *__restrict__ delta, size_t sAB, size_t sP, size_t sDelta,
+                                                           int gx, int gy, int ntiles) {
     // work-group id -> (pair, A tile row, B tile column), see "Tile order" above
     int rowA0, rowB0;
+    const unsigned char *Ab, *Bb;             // the tile's first blocks: stage it = block it of the row block
     {
         const int per = gridDim.x >> 3;
         const int L = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
@@ -164,12 +205,19 @@ __global__ __launch_bounds__(256) void corr_pool_kernel(const unsigned short *__
         P += (size_t)z * sP;
         if (delta) delta += (size_t)z * sDelta;
         rowA0 = arow * CT; rowB0 = bcol * CT;
+        Ab = (const unsigned char *)A + (size_t)arow * (C >> 5) * CX_BLK;
+        Bb = (const unsigned char *)B + (size_t)bcol * (C >> 5) * CX_BLK;
     }
     P2P_DYN_SHARED(unsigned char, cx);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
-    const size_t plA = (size_t)nA * C, plB = (size_t)nB * C;       // plane strides in elements
+    const unsigned lane16 = wave * 4096 + lane * 16;
+    // fragment addresses inside a block: row r, piece (2 slab + half) ^ ((r >> 2) & 3)
+    const int sw = (l31 >> 2) & 3;
+    const unsigned aoff0 = ((wr * 64 + l31) * 4 + ((0 + half) ^ sw)) * 16, aoff1 = ((wr * 64 + l31) * 4 + ((2 + half) ^ sw)) * 16;
+    const unsigned boff0 = ((wc * 64 + l31) * 4 + ((0 + half) ^ sw)) * 16, boff1 = ((wc * 64 + l31) * 4 + ((2 + half) ^ sw)) * 16;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -177,59 +225,36 @@ __global__ __launch_bounds__(256) void corr_pool_kernel(const unsigned short *__
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
 
-    // loader: per plane and matrix 128 rows x 64 B = 512 16-byte pieces: thread -> pieces tid and tid + 256
-    const int lrow = tid >> 2, lq = tid & 3;
-    f32x4 va[2][2], vb[2][2];
-    auto load = [&](int k0) {
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = lrow + 64 * i;
-                const int ra = min(rowA0 + r, nA - 1), rb = min(rowB0 + r, nB - 1);
-                va[pl][i] = *(const f32x4 *)(A + pl * plA + (size_t)ra * C + k0 + lq * 8);
-                vb[pl][i] = *(const f32x4 *)(B + pl * plB + (size_t)rb * C + k0 + lq * 8);
-            }
-    };
-    auto store = [&](unsigned char *st) {
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = lrow + 64 * i;
-                *(f32x4 *)(st + pl * CX_PLANE + r * CX_ROW + lq * 16) = va[pl][i];
-                *(f32x4 *)(st + CX_MAT + pl * CX_PLANE + r * CX_ROW + lq * 16) = vb[pl][i];
-            }
-    };
-    load(0);
-    store(cx);
-    __syncthreads();
+    f32x4 xa[2][2], xb[2][2], ya[2][2], yb[2][2];
     const int nk = C / 32;
-    for (int it = 0; it < nk; ++it) {
-        const unsigned char *st = cx + (it & 1) * CX_STAGE;
-        if (it + 1 < nk) load((it + 1) * 32);          // in flight while this stage is multiplied
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {     // two slabs of 16 K
-            f32x4 a[2][2], b[2][2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-                    a[i][pl] = *(const f32x4 *)(st + pl * CX_PLANE + (wr * 64 + i * 32 + l31) * CX_ROW + kk * 32 + half * 16);
-                    b[i][pl] = *(const f32x4 *)(st + CX_MAT + pl * CX_PLANE + (wc * 64 + i * 32 + l31) * CX_ROW + kk * 32 + half * 16);
-                }
-            // smallest terms first (a1 b0, a0 b1, a0 b0); the four accumulators rotate
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const int pa = (t == 0) ? 1 : 0, pb = (t == 1) ? 1 : 0;
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = cx_mfma(a[i][pa], b[j][pb], acc[i][j]);
-            }
-        }
-        if (it + 1 < nk) store(cx + ((it + 1) & 1) * CX_STAGE);     // the other stage: everybody left it at the last barrier
-        __syncthreads();
+    CX_ISSUE(0, 0)
+#pragma unroll 1
+    for (int it = 0; it < nk; it += 2) {
+        // even stage (slot 0): its pieces have landed for everybody behind the barrier, and everybody is done with slot 1
+        P2P_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 < nk) CX_ISSUE(it + 1, 1)
+        CX_READ(xa, xb, 0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        CX_READ(ya, yb, 0, 1)
+        CX_SLAB(xa, xb)
+        CX_PIPE()
+        CX_SLAB(ya, yb)
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 >= nk) break;
+        // odd stage (slot 1)
+        P2P_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 2 < nk) CX_ISSUE(it + 2, 0)
+        CX_READ(xa, xb, 1, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        CX_READ(ya, yb, 1, 1)
+        CX_SLAB(xa, xb)
+        CX_PIPE()
+        CX_SLAB(ya, yb)
+        __builtin_amdgcn_sched_barrier(0);
     }
     // the planes carried 2^12 each: the accumulators hold 2^24 x the correlation (undone exactly at the stores; a maximum
     // commutes with the positive power of two)
@@ -548,8 +573,8 @@ static CoarseWs coarse_ws(int C, int hA, int wA, int hB, int wB, int k) {
     const size_t nAc = nA / (k * k), nBc = nB / (k * k);
     CoarseWs w;
     size_t off = 0;
-    w.fnA = off; off += al(nA * C * 4);      // two fp16 planes [pos'][C]
-    w.fnB = off; off += al(nB * C * 4);
+    w.fnA = off; off += al(((nA + 127) / 128) * 128 * C * 4);      // two fp16 planes in blocks of 128 positions x 32 channels
+    w.fnB = off; off += al(((nB + 127) / 128) * 128 * C * 4);
     w.P = off; off += al(nAc * nBc * 4);
     w.Y = off; off += al(nAc * nBc * 4);     // the two branches of the consensus net
     w.Y2 = off; off += al(nAc * nBc * 4);
@@ -593,6 +618,10 @@ extern "C" int p2p_ncn_create(const float *w1, const float *b1, const float *w2,
 
 extern "C" int p2p_ncn_set_tile(p2p_ncn *ncn, int ta, int tb, int tc) {
     P2P_REQUIRE(ncn && ta >= 0 && tb >= 0 && tc >= 0, P2P_EINVAL, "p2p_ncn_set_tile: bad argument");
+    // (0, 0, 0) = automatic; (ta, tb, tc) with tb, tc > 0 = forced (ta = 0: only the march length is picked); anything else
+    // would be ignored silently
+    P2P_REQUIRE((tb > 0 && tc > 0) || (ta == 0 && tb == 0 && tc == 0), P2P_EINVAL,
+                "p2p_ncn_set_tile: (%d, %d, %d) is neither (0, 0, 0) nor a tile with tb, tc > 0", ta, tb, tc);
     ncn->tile[0] = ta; ncn->tile[1] = tb; ncn->tile[2] = tc;
     return P2P_OK;
 }

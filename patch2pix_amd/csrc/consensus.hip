@@ -686,6 +686,9 @@ static long nc_fused_tile(NcFusedArgs &a, int pairs, const int *forced) {
 int launch_nc_fused(const float *X, float *Y, float *Y2, size_t stride, int pairs, int d0, int d1, int d2, int d3,
                     const unsigned char *w_dev, float b2, const int *xmax, size_t xmax_stride, const int *forced_tile,
                     hipStream_t stream) {
+    // the flush computes output offsets in 32 bits
+    P2P_REQUIRE((unsigned long long)d0 * d1 * d2 * d3 < (1ull << 31), P2P_EUNSUPPORTED,
+                "consensus volume %d x %d x %d x %d has 2^31 cells or more", d0, d1, d2, d3);
     NcFusedArgs a{};
     a.X = X; a.Y = Y; a.Y2 = Y2; a.stride = stride; a.d0 = d0; a.d1 = d1; a.d2 = d2; a.d3 = d3; a.w = w_dev; a.b2 = b2;
     a.xmax = xmax; a.xmax_stride = xmax_stride;

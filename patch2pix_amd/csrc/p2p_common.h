@@ -7,6 +7,20 @@
 #include <vector>
 #include "../../include/p2p_hip.h"
 
+// Timing experiments (kernel variants that drop or pin a part of the work, phase stamps; most of them produce WRONG results
+// by design) exist only behind -DP2P_EXPERIMENT: such a build reports P2P_VERSION_EXPERIMENT in p2p_version() and the
+// Python binding refuses to load it unless P2P_ALLOW_EXPERIMENT=1 is set (tools/ab_variants.sh does).  A product build with
+// one of the switches defined does not compile.
+#if !defined(P2P_EXPERIMENT) &&                                                                                          \
+    (defined(XF_PIN_W) || defined(XF_SAME_PATCH) || defined(XF_SKIP_P) || defined(XF_SKIP_C) || defined(XF_SKIP_FOLD) ||   \
+     defined(XF_SKIP_CONV2) || defined(XF_CONV2_HALF) || defined(XF_SKIP_FC) || defined(XF_GRID_CAP) || defined(XF_TURN4) || \
+     defined(XF_WINO_NOSTORE) || defined(XF_WINO_NT) || defined(XF_WINO_STAGGER) || defined(P2P_WINO_CHUNK) || defined(XF_WINO_NOXF) || defined(XF_WINO_NOFOLD) || defined(XF_WINO_NODMA) ||           \
+     defined(P2P_X3_TIMING) || defined(XF_TURNS1) || defined(XF_TURNS2) || defined(XP_VALU) || defined(XH_BURST) ||       \
+     defined(XH_NOSNAKE))
+#error "experiment switches (XF_*, XH_*, XP_*, P2P_X3_TIMING) need -DP2P_EXPERIMENT: the library then identifies itself as an experiment build"
+#endif
+#define P2P_VERSION_EXPERIMENT 0x40000000
+
 namespace p2p {
 
 void set_error(const char *fmt, ...);
@@ -95,6 +109,7 @@ struct p2p_ncn {
 };
 
 struct p2p_regressor {
+    int device;        // the device the handle was created on: every later allocation (another mode's weight stream) goes there
     float *dev;        // BatchNorm folds + FC layers (every mode)
     float *dev_p, *dev_h, *dev_w;   // the convolution weights in the stream order of the f32 / fp16x2 / fp16x2w kernels; packed on
                                     // the first selection of that mode (p2p_regressor_set_mode), null until then

@@ -430,7 +430,12 @@ extern "C" int p2p_regressor_set_mode(p2p_regressor *reg, int mode) {
     P2P_REQUIRE(reg, P2P_EINVAL, "p2p_regressor_set_mode: null handle");
     P2P_REQUIRE(mode == P2P_REGRESS_F32 || mode == P2P_REGRESS_FP16X2 || mode == P2P_REGRESS_FP16X2W, P2P_EINVAL,
                 "p2p_regressor_set_mode: unknown mode %d", mode);
+    // the weight stream of a mode is allocated on the HANDLE's device, whatever the caller's current device is
+    int cur = 0;
+    P2P_HIP_CHECK(hipGetDevice(&cur));
+    if (cur != reg->device) P2P_HIP_CHECK(hipSetDevice(reg->device));
     const int st = ensure_mode(reg, mode);
+    if (cur != reg->device) P2P_HIP_CHECK(hipSetDevice(cur));
     if (st != P2P_OK) return st;
     reg->mode = mode;
     return P2P_OK;
@@ -476,6 +481,8 @@ extern "C" int p2p_regressor_create(const p2p_regressor_params *p, p2p_regressor
     int st = upload(h, &dev, "the regressor's BatchNorm / FC parameters");
     if (st != P2P_OK) return st;
     p2p_regressor *r = new p2p_regressor();
+    r->device = 0;
+    (void)hipGetDevice(&r->device);
     r->dev = dev;
     r->dev_p = r->dev_h = r->dev_w = nullptr;
     r->ww2 = r->bn2s_w = r->wp1 = r->wp2 = r->wh1 = r->wh2 = r->bn1s_h = r->bn2s_h = nullptr;

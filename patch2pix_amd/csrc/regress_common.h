@@ -49,7 +49,10 @@ constexpr int FC_ROWS = 16;             // proposals per FC batch = rows of a v_
 // most WINO_CHUNK proposals (16 positions x 16 tiles x 512 channels x 2 fp16 planes = 512 KiB per proposal), as the A
 // blocks of wino_gemm_kernel: [position 16][row block of 8 proposals][K chunk 16][WINO_BLK bytes]
 constexpr int WINO_BLK = 16384;         // [plane 2][row 128][32 K] fp16
-constexpr int WINO_CHUNK = 2048;        // proposals per conv1 -> GEMM round (a whole number of rounds of both kernels on 256 CUs)
+#ifndef P2P_WINO_CHUNK
+#define P2P_WINO_CHUNK 2048
+#endif
+constexpr int WINO_CHUNK = P2P_WINO_CHUNK;   // proposals per conv1 -> GEMM round (a whole number of rounds of both kernels on 256 CUs)
 static inline size_t regress_ws_base_floats(size_t n) { return ((2 * n * 512 + 31) & ~size_t(31)) + 4 * n + 32; }
 static inline size_t wino_hinv_offset_floats(size_t n) { return (regress_ws_base_floats(n) + 63) & ~size_t(63); }
 static inline size_t wino_chunk_rows(size_t n) { return (std::min(n, (size_t)WINO_CHUNK) + 7) & ~size_t(7); }
@@ -69,6 +72,21 @@ __device__ __forceinline__ int level_dim(int dim, int j) { return (dim + (1 << j
 __device__ __forceinline__ int patch_cell(int origin, int p, int j, int dim) {
     const int d = dim >> j;
     return clampi((origin + p) >> j, 0, d - 1) - clampi(origin >> j, 0, d - 1);
+}
+
+// P2P_REGRESS_FP16X2W walks the proposals that EXIST: compact index c (0, 1, ... in item order; with device-side counts the
+// first dev_counts[i] slots of every item) -> slot in the concatenated arrays, or -1 past the last one.  Its scratch rows
+// (the transformed conv2 input, the inverse scales) are indexed by c, so that empty slots cost no GEMM rows.
+template <class A>
+__device__ __forceinline__ int wino_slot(const A &a, int c) {
+    if (!a.dev_counts) return c < a.n ? c : -1;
+    int cum = 0;
+    for (int it = 0; it < a.nitems; ++it) {
+        const int cnt = min(a.dev_counts[it], a.start[it + 1] - a.start[it]);
+        if (c < cum + cnt) return a.start[it] + (c - cum);
+        cum += cnt;
+    }
+    return -1;
 }
 
 // FC 512->512->256->5 with folded BatchNorm1d + ReLU (networks/modules.py:89-99), then

@@ -365,6 +365,9 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwg = gridDim.x;
 
+#ifdef XF_WINO_STAGGER                   // timing experiment: start the work-groups in XF_WINO_STAGGER phases, XF_WINO_STAGGER_US apart
+    if (WINO) for (int i = 0; i < (int)((blockIdx.x >> 3) % XF_WINO_STAGGER) * (XF_WINO_STAGGER_US / 4); ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     float *raw0 = (float *)(smb + XRAW0);
     float *scale = (float *)(smb + XSM_SCALE);
     float *misc = (float *)(smb + XSM_MISC);
@@ -377,10 +380,13 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
     for (int lvl = WINO ? args.lvl0 : 0; lvl < (WINO ? args.lvl0 + 1 : args.nlevels); ++lvl) {
         const RegDev &R_ = args.reg[lvl];
 #pragma unroll 1
-      for (int prop = (WINO ? args.p0 : 0) + blockIdx.x; prop < (WINO ? args.p1 : args.n); prop += nwg) {
+      for (int cprop = (WINO ? args.p0 : 0) + blockIdx.x; cprop < (WINO ? args.p1 : args.n); cprop += nwg) {
+        // WINO: cprop is the compact index of a proposal that exists (its scratch rows), prop its slot; else they coincide
+        const int prop = WINO ? wino_slot(args, cprop) : cprop;
+        if (WINO && prop < 0) break;
         int it = 0;
         while (it + 1 < args.nitems && prop >= args.start[it + 1]) ++it;
-        if (args.dev_counts && prop - args.start[it] >= args.dev_counts[it]) continue;      // empty slot (whole work-group)
+        if (!WINO && args.dev_counts && prop - args.start[it] >= args.dev_counts[it]) continue;      // empty slot (whole work-group)
         const ItemDev &I = args.item[it];
         if (tid < 4) {
             float v;
@@ -778,7 +784,7 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
             // |H| * hmul in [2^10, 2^11): the transform grows a value at most fourfold, |U| < 2^13
             const int eb = clampi((((const int *)misc)[14] >> 23) & 0xff, 20, 250);
             const float hmul = __int_as_float((264 - eb) << 23);
-            if (tidv == 0) args.hinv[prop - args.p0] = __int_as_float((eb - 10) << 23);
+            if (tidv == 0) args.hinv[cprop - args.p0] = __int_as_float((eb - 10) << 23);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int n = wave * 64 + u * 32 + l31;
@@ -794,49 +800,82 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                 }
             }
             __syncthreads();
-            // item = (half of the tiles, K chunk of 32 channels): lane = (tile of the half, 4 channels); 4 items per wave
-            const int lq = tidv & 63, cq = lq & 7;
-            const unsigned pl = (unsigned)(prop - args.p0);
+            XT(8)
+            // item = K chunk of 32 channels: lane = (tile, 8 channels), two passes of 4 channels; a lane's 8 values of a
+            // (position, plane) are ONE 16-byte store and a wave's store covers the proposal's 16 rows of a block = 1 KiB
+            // contiguous (8-byte stores in 64-byte runs cost 2 ms of a 14.5 ms launch in write bandwidth)
+            const int lq = tidv & 63, oct = lq & 3, tile = lq >> 2, ty = tile >> 2, tx = tile & 3;
+            const unsigned pl = (unsigned)(cprop - args.p0);
+#ifdef XF_WINO_NOSTORE                   // timing experiment (wrong results): every store of the transform lands in one 32 KB window
+            const unsigned pstride = 0;
+#else
             const unsigned pstride = (unsigned)args.mblocks * (16u * WINO_BLK);
-#pragma unroll 1
-            for (int i4 = 0; i4 < 4; ++i4) {
-                const int item = wave * 4 + i4, kc = item & 15;
-                const int tile = 8 * (item >> 4) + (lq >> 3), ty = tile >> 2, tx = tile & 3;
-                f32x4 d[4][4];
+#endif
+            const unsigned rr = (pl & 7u) * 16u + (unsigned)tile;
+            const unsigned inblk = (rr * 4u + ((unsigned)oct ^ ((rr >> 2) & 3u))) * 16u;
+            int pxo[4][4];                                        // LDS offsets of the window (outside the map: the zero row)
 #pragma unroll
-                for (int aa = 0; aa < 4; ++aa)
-#pragma unroll
-                    for (int bb = 0; bb < 4; ++bb) {
-                        const int y = 2 * ty + aa - 1, x = 2 * tx + bb - 1;
-                        const int px = ((unsigned)y < 8u && (unsigned)x < 8u) ? y * 8 + x : 64;
-                        d[aa][bb] = *(const f32x4 *)(smb + px * HWST + (kc * 32 + cq * 4) * 4);
-                    }
-                // B^T d B,  B^T = [[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]]
-                f32x4 tr[4][4];
+            for (int aa = 0; aa < 4; ++aa)
 #pragma unroll
                 for (int bb = 0; bb < 4; ++bb) {
-                    tr[0][bb] = d[0][bb] - d[2][bb];
-                    tr[1][bb] = d[1][bb] + d[2][bb];
-                    tr[2][bb] = d[2][bb] - d[1][bb];
-                    tr[3][bb] = d[1][bb] - d[3][bb];
+                    const int y = 2 * ty + aa - 1, x = 2 * tx + bb - 1;
+                    pxo[aa][bb] = (((unsigned)y < 8u && (unsigned)x < 8u) ? y * 8 + x : 64) * HWST + oct * 32;
                 }
-                const unsigned rr = (pl & 7u) * 16u + (unsigned)tile;
-                const unsigned inblk = (rr * 4u + (((unsigned)cq >> 1) ^ ((rr >> 2) & 3u))) * 16u + ((unsigned)cq & 1u) * 8u;
+#ifdef XF_WINO_NOXF                      // timing experiments (wrong results): no transform pass / no stores of its results
+            if (args.n < 0)
+#endif
+#pragma unroll 1
+            for (int i2 = 0; i2 < 2; ++i2) {
+                const int kc = wave * 2 + i2;
+#ifdef XF_WINO_NOSTORE
+                unsigned char *ub = args.wU + (size_t)inblk;
+#else
                 unsigned char *ub = args.wU + (size_t)(((pl >> 3) * 16u + (unsigned)kc) * (unsigned)WINO_BLK + inblk);
+#endif
+                unsigned keep[16][4];                             // first pass: {h0a, h0b, h1a, h1b} of channels 0-3
 #pragma unroll
-                for (int ii = 0; ii < 4; ++ii)
+                for (int hh = 0; hh < 2; ++hh) {
+                    f32x4 d[4][4];
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        const f32x4 v = (jj == 0) ? tr[ii][0] - tr[ii][2] : (jj == 1) ? tr[ii][1] + tr[ii][2]
-                                      : (jj == 2) ? tr[ii][2] - tr[ii][1] : tr[ii][1] - tr[ii][3];
-                        const unsigned h0a = pk_e(v[0], v[1]), h0b = pk_e(v[2], v[3]);
-                        const unsigned h1a = pk_e(v[0] - pk_lo(h0a), v[1] - pk_hi(h0a));
-                        const unsigned h1b = pk_e(v[2] - pk_lo(h0b), v[3] - pk_hi(h0b));
-                        unsigned char *dst = ub + (size_t)(ii * 4 + jj) * pstride;
-                        *(uint2 *)dst = make_uint2(h0a, h0b);
-                        *(uint2 *)(dst + WINO_BLK / 2) = make_uint2(h1a, h1b);
+                    for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+                        for (int bb = 0; bb < 4; ++bb) d[aa][bb] = *(const f32x4 *)(smb + pxo[aa][bb] + kc * 128 + hh * 16);
+                    // B^T d B,  B^T = [[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]]
+                    f32x4 tr[4][4];
+#pragma unroll
+                    for (int bb = 0; bb < 4; ++bb) {
+                        tr[0][bb] = d[0][bb] - d[2][bb];
+                        tr[1][bb] = d[1][bb] + d[2][bb];
+                        tr[2][bb] = d[2][bb] - d[1][bb];
+                        tr[3][bb] = d[1][bb] - d[3][bb];
                     }
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const f32x4 v = (jj == 0) ? tr[ii][0] - tr[ii][2] : (jj == 1) ? tr[ii][1] + tr[ii][2]
+                                          : (jj == 2) ? tr[ii][2] - tr[ii][1] : tr[ii][1] - tr[ii][3];
+                            const unsigned h0a = pk_e(v[0], v[1]), h0b = pk_e(v[2], v[3]);
+                            const unsigned h1a = pk_e(v[0] - pk_lo(h0a), v[1] - pk_hi(h0a));
+                            const unsigned h1b = pk_e(v[2] - pk_lo(h0b), v[3] - pk_hi(h0b));
+                            unsigned *kp = keep[ii * 4 + jj];
+                            if (hh == 0) {
+                                kp[0] = h0a; kp[1] = h0b; kp[2] = h1a; kp[3] = h1b;
+                            } else {
+                                unsigned char *dst = ub + (size_t)(ii * 4 + jj) * pstride;
+#ifdef XF_WINO_NT
+                                typedef unsigned nt_u4 __attribute__((ext_vector_type(4)));
+                                __builtin_nontemporal_store((nt_u4){kp[0], kp[1], h0a, h0b}, (nt_u4 *)dst);
+                                __builtin_nontemporal_store((nt_u4){kp[2], kp[3], h1a, h1b}, (nt_u4 *)(dst + WINO_BLK / 2));
+#else
+                                *(uint4 *)dst = make_uint4(kp[0], kp[1], h0a, h0b);
+                                *(uint4 *)(dst + WINO_BLK / 2) = make_uint4(kp[2], kp[3], h1a, h1b);
+#endif
+                            }
+                        }
+                }
             }
+            XT(9)
         } else {
         // BN1 -> H.  Two planes: every wave writes the planes of its 64 channels into its chunk (wave >> 1).  Three planes:
         // chunk 0 (channels of waves 0, 1) as planes, the other chunks wait as fp32

@@ -16,9 +16,9 @@
 //   Y[a][b] += A^T[a][i] A^T[b][j] M_p   (coefficients 0, +-1: exact)      the 2 x 2 outputs of the tile
 //   V[proposal][n] = max(0, max over tiles and (a, b) of bn2(Y))            (BN before the max: its scale may be negative)
 //
-// wino_gemm_kernel.  Work-group = 128 rows (8 proposals x 16 tiles) x 128 output channels, 4 waves (one per SIMD: the
-// accumulators M (64) + Y (256) need the 512-register budget of a single wave per SIMD), each a 64 x 64 tile = 2 x 2 MFMA
-// tiles.  K = 16 positions x 512 channels is walked in 256 stages of 32 channels; a stage's operands are two 16 KB blocks
+// wino_gemm_kernel.  Work-group = 128 rows (8 proposals x 16 tiles) x 128 output channels, 8 waves (two per SIMD: issuing an
+// LDS-DMA piece stalls a wave for ~60-100 cycles, longer than an MFMA lasts, so a single wave per SIMD left the matrix pipe
+// 45 % busy; its sibling now issues meanwhile), each a 64 x 32 tile = 2 x 1 MFMA tiles: M (32) + Y (128) accumulators.  K = 16 positions x 512 channels is walked in 256 stages of 32 channels; a stage's operands are two 16 KB blocks
 // (A: U rows, B: filters) whose GLOBAL layout is the LDS image -- [plane 2][row 128][4 pieces of 16 B], piece q of a row
 // stored at slot q ^ ((row >> 2) & 3), which puts the 16 lanes of every ds_read_b128 service group on 16 different bank
 // slots -- so they are copied by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write) into a ring of four
@@ -37,7 +37,7 @@ namespace p2p {
 typedef _Float16 we8 __attribute__((ext_vector_type(8)));
 #define WMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(we8, (a)), __builtin_bit_cast(we8, (b)), (c), 0, 0, 0)
 
-constexpr int WNT = 256;                 // threads per work-group
+constexpr int WNT = 512;                 // threads per work-group: 8 waves, two per SIMD
 constexpr int WSTAGE = 2 * WINO_BLK;     // A block + B block
 constexpr int WRING = 4;
 constexpr int WLDS = WRING * WSTAGE;     // 128 KB
@@ -50,51 +50,56 @@ struct WinoArgs {
     const float *hinv;           // per proposal of the chunk: inverse of the power of two its H was scaled by
     float *V;                    // pooled features [n][512] of the level
     int mblocks;                 // row blocks of the chunk
-    int p0, n;                   // first proposal of the chunk, proposals of the launch (rows beyond n are padding)
+    int p0, n;                   // first (compact) proposal index of the chunk; slots of the launch
+    // compact index -> slot (wino_slot): the item table of the launch
+    const int *dev_counts;
+    int nitems;
+    int start[MAXB + 1];
 };
 
-// one stage = 8 LDS-DMA pieces of 1 KiB per wave: wave w copies bytes [4096 w, 4096 w + 4096) of the A and of the B block
+// one stage = 4 LDS-DMA pieces of 1 KiB per wave: wave w copies bytes [2048 w, 2048 w + 2048) of the A and of the B block
 #define WISSUE(ST, SLOT)                                                                                               \
     {                                                                                                                  \
         const int st_ = (ST) < 256 ? (ST) : 255;          /* past the end: reload the last stage into a free slot */  \
         const int p_ = st_ >> 4, kc_ = st_ & 15;                                                                       \
-        const unsigned char *ga_ = a.U + ((size_t)(p_ * a.mblocks + mb) * 16 + kc_) * WINO_BLK + woff;                   \
+        const unsigned char *ga_ = a.U + ((size_t)(p_ * a.mblocks + mb) * 16 + kc_) * WINO_BLK + woff;                  \
         const unsigned char *gb_ = a.Wt + ((size_t)((p_ * 4 + nb) * 16 + kc_)) * WINO_BLK + woff;                       \
-        unsigned char *la_ = smb + (SLOT) * WSTAGE + wave * 4096;                                                      \
+        unsigned char *la_ = smb + (SLOT) * WSTAGE + wave * 2048;                                                      \
         P2P_GLOBAL_LOAD_LDS16(ga_ + lane16, la_, 0); P2P_GLOBAL_LOAD_LDS16(ga_ + lane16, la_, 1024);                   \
-        P2P_GLOBAL_LOAD_LDS16(ga_ + lane16, la_, 2048); P2P_GLOBAL_LOAD_LDS16(ga_ + lane16, la_, 3072);                \
         P2P_GLOBAL_LOAD_LDS16(gb_ + lane16, la_ + WINO_BLK, 0); P2P_GLOBAL_LOAD_LDS16(gb_ + lane16, la_ + WINO_BLK, 1024); \
-        P2P_GLOBAL_LOAD_LDS16(gb_ + lane16, la_ + WINO_BLK, 2048); P2P_GLOBAL_LOAD_LDS16(gb_ + lane16, la_ + WINO_BLK, 3072); \
     }
-// fragments of slab S (0, 1) of ring slot SLOT: A[m-tile][plane], B[n-tile][plane]
+// fragments of slab S (0, 1) of ring slot SLOT: A[m-tile][plane], B[plane]
 #define WREAD(FA, FB, SLOT, S)                                                                                         \
     {                                                                                                                  \
         const unsigned char *pa_ = smb + (SLOT) * WSTAGE + ((S) ? aoff1 : aoff0);                                      \
         const unsigned char *pb_ = smb + (SLOT) * WSTAGE + WINO_BLK + ((S) ? boff1 : boff0);                            \
-        _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_)                                                               \
-            _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                                         \
-                FA[t_][q_] = *(const f32x4 *)(pa_ + t_ * 2048 + q_ * 8192);                                            \
-                FB[t_][q_] = *(const f32x4 *)(pb_ + t_ * 2048 + q_ * 8192);                                            \
-            }                                                                                                          \
+        _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                                             \
+            FA[0][q_] = *(const f32x4 *)(pa_ + q_ * 8192);                                                             \
+            FA[1][q_] = *(const f32x4 *)(pa_ + 2048 + q_ * 8192);                                                      \
+            FB[q_] = *(const f32x4 *)(pb_ + q_ * 8192);                                                                \
+        }                                                                                                              \
     }
-// 12 MFMAs of a slab; smallest terms first; consecutive instructions share an operand, the four accumulators rotate
-#define WQUAD(FA, FB, P, Q, C00, C01, C10, C11)                                                                        \
-    M00 = WMFMA(FA[0][P], FB[0][Q], C00); M01 = WMFMA(FA[0][P], FB[1][Q], C01);                                        \
-    M11 = WMFMA(FA[1][P], FB[1][Q], C11); M10 = WMFMA(FA[1][P], FB[0][Q], C10);
-#define WSLAB(FA, FB) WQUAD(FA, FB, 1, 0, M00, M01, M10, M11) WQUAD(FA, FB, 0, 1, M00, M01, M10, M11) WQUAD(FA, FB, 0, 0, M00, M01, M10, M11)
-#define WSLABZ(FA, FB) WQUAD(FA, FB, 1, 0, zero16, zero16, zero16, zero16) WQUAD(FA, FB, 0, 1, M00, M01, M10, M11) WQUAD(FA, FB, 0, 0, M00, M01, M10, M11)
+// 6 MFMAs of a slab; smallest terms first; the two accumulators alternate
+#define WSLAB_(FA, FB, C0, C1)                                                                                         \
+    M0 = WMFMA(FA[0][1], FB[0], C0); M1 = WMFMA(FA[1][1], FB[0], C1);                                                  \
+    M0 = WMFMA(FA[0][0], FB[1], M0); M1 = WMFMA(FA[1][0], FB[1], M1);                                                  \
+    M0 = WMFMA(FA[0][0], FB[0], M0); M1 = WMFMA(FA[1][0], FB[0], M1);
+#define WSLAB(FA, FB) WSLAB_(FA, FB, M0, M1)
+#define WSLABZ(FA, FB) WSLAB_(FA, FB, zero16, zero16)
 
 // The compiler folds a software prefetch back into read -> wait -> MFMA chains unless the interleave is pinned: one LDS read
-// (and, in the half of a stage that issues the next DMA, one LDS-DMA piece) behind each of the first eight MFMAs of a slab.
+// (and, in the half of a stage that issues the next DMA, LDS-DMA pieces) behind each MFMA of a slab.
 #define WPIPE_A()                                                                                                      \
-    _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                                                 \
+    _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                                                                 \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }        \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);
 #define WPIPE_B()                                                                                                      \
-    _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                                                 \
+    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                                 \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);          \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }                                                           \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_barrier(0);
+    _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) {                                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }        \
+    __builtin_amdgcn_sched_barrier(0);
 
 __global__ __launch_bounds__(WNT, 1) void wino_gemm_kernel(WinoArgs a) {
     P2P_DYN_SHARED(unsigned char, smb);
@@ -104,33 +109,31 @@ __global__ __launch_bounds__(WNT, 1) void wino_gemm_kernel(WinoArgs a) {
     // work-group g runs on XCD g mod 8: the four column blocks of a row block are neighbours there
     const int g = blockIdx.x, xcd = g & 7, q = g >> 3;
     const int nb = q & 3, mb = (q >> 2) * 8 + xcd;
-    if (mb >= a.mblocks) return;
-    const int wm = wave >> 1, wn = wave & 1;
-    const unsigned lane16 = lane * 16, woff = wave * 4096;
+    if (mb >= a.mblocks || wino_slot(a, a.p0 + mb * 8) < 0) return;      // no row block, or none of its proposals exists
+    const int wm = wave >> 2, wn = wave & 3;          // this wave's tile: rows [64 wm, +64), columns [32 wn, +32)
+    const unsigned lane16 = lane * 16, woff = wave * 2048;
     // fragment addresses inside a block: row r, piece (2 slab + half) ^ ((r >> 2) & 3)
     const int sw = (l31 >> 2) & 3;
     const unsigned aoff0 = ((wm * 64 + l31) * 4 + ((0 + half) ^ sw)) * 16, aoff1 = ((wm * 64 + l31) * 4 + ((2 + half) ^ sw)) * 16;
-    const unsigned boff0 = ((wn * 64 + l31) * 4 + ((0 + half) ^ sw)) * 16, boff1 = ((wn * 64 + l31) * 4 + ((2 + half) ^ sw)) * 16;
+    const unsigned boff0 = ((wn * 32 + l31) * 4 + ((0 + half) ^ sw)) * 16, boff1 = ((wn * 32 + l31) * 4 + ((2 + half) ^ sw)) * 16;
 
     const f32x16 zero16 = {0};
-    f32x16 Y[4][2][2];
+    f32x16 Y[4][2];
 #pragma unroll
     for (int ab = 0; ab < 4; ++ab)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) Y[ab][t][u] = zero16;
-    f32x4 XA[2][2], XB[2][2], YA[2][2], YB[2][2];
+        for (int t = 0; t < 2; ++t) Y[ab][t] = zero16;
+    f32x4 XA[2][2], XB[2], YA[2][2], YB[2];
 
     WISSUE(0, 0) WISSUE(1, 1) WISSUE(2, 2)
-    P2P_WAIT_VMCNT(16);
+    P2P_WAIT_VMCNT(8);
     __builtin_amdgcn_s_barrier();
     WREAD(XA, XB, 0, 0)
     __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll 1
     for (int p = 0; p < 16; ++p) {
-        f32x16 M00, M01, M10, M11;
+        f32x16 M0, M1;
 #pragma unroll
         for (int kc = 0; kc < 16; ++kc) {
             const int slot = kc & 3;
@@ -140,9 +143,12 @@ __global__ __launch_bounds__(WNT, 1) void wino_gemm_kernel(WinoArgs a) {
             WPIPE_A()
             // stage st + 1 has landed (this wave's pieces; the barrier extends that to everybody's) and every wave is
             // past stage st - 1, whose slot stage st + 3 overwrites
-            P2P_WAIT_VMCNT(8);
+            P2P_WAIT_VMCNT(4);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+#ifdef XF_WINO_NODMA                    // timing experiment (wrong results): the ring is never refilled
+            if (a.n < 0)
+#endif
             WISSUE(p * 16 + kc + 3, (kc + 3) & 3)
             // slab 1, behind it the reads of the next stage's slab 0
             WREAD(XA, XB, (kc + 1) & 3, 0)
@@ -150,6 +156,9 @@ __global__ __launch_bounds__(WNT, 1) void wino_gemm_kernel(WinoArgs a) {
             WPIPE_B()
         }
         // Y[a][b] += A^T[a][i] A^T[b][j] M,   A^T = [[1, 1, 1, 0], [0, 1, -1, -1]]
+#ifdef XF_WINO_NOFOLD                   // timing experiment (wrong results): only the last position is folded
+        if (p == 15)
+#endif
         {
             const int i = p >> 2, j = p & 3;
             const float ca[2] = {(i < 3) ? 1.f : 0.f, (i == 0) ? 0.f : (i == 1) ? 1.f : -1.f};
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(WNT, 1) void wino_gemm_kernel(WinoArgs a) {
 #pragma unroll
             for (int ab = 0; ab < 4; ++ab) {
                 const float c = ca[ab >> 1] * cb[ab & 1];
-                Y[ab][0][0] += c * M00; Y[ab][0][1] += c * M01; Y[ab][1][0] += c * M10; Y[ab][1][1] += c * M11;
+                Y[ab][0] += c * M0; Y[ab][1] += c * M1;
             }
         }
     }
@@ -165,24 +174,22 @@ __global__ __launch_bounds__(WNT, 1) void wino_gemm_kernel(WinoArgs a) {
 
     // BN2 -> ReLU -> max over the 16 tiles x 4 outputs of each proposal.  Register r of an accumulator is row
     // (r & 3) + 8 (r >> 2) + 4 half of its m-tile: r < 8 belongs to the m-tile's first proposal, r >= 8 to its second.
+    const int n = nb * 128 + wn * 32 + l31;
+    const float s = a.bn2s[n], b = a.bn2b[n];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int n = nb * 128 + wn * 64 + u * 32 + l31;
-            const float s = a.bn2s[n], b = a.bn2b[n];
+        for (int gq = 0; gq < 2; ++gq) {
+            const int pl = mb * 8 + wm * 4 + 2 * t + gq;          // proposal inside the chunk
+            const int slot = wino_slot(a, a.p0 + pl);
+            const float hs = s * a.hinv[pl];
+            float m = 0.f;
 #pragma unroll
-            for (int gq = 0; gq < 2; ++gq) {
-                const int pl = mb * 8 + wm * 4 + 2 * t + gq;          // proposal inside the chunk
-                const float hs = s * a.hinv[pl];
-                float m = 0.f;
+            for (int ab = 0; ab < 4; ++ab)
 #pragma unroll
-                for (int ab = 0; ab < 4; ++ab)
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) m = fmaxf(m, fmaf(Y[ab][t][u][8 * gq + r], hs, b));
-                m = fmaxf(m, __shfl_xor(m, 32));
-                if (half == 0 && a.p0 + pl < a.n) a.V[(size_t)(a.p0 + pl) * 512 + n] = m;
-            }
+                for (int r = 0; r < 8; ++r) m = fmaxf(m, fmaf(Y[ab][t][8 * gq + r], hs, b));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            if (half == 0 && slot >= 0) a.V[(size_t)slot * 512 + n] = m;
         }
 }
 
@@ -268,6 +275,8 @@ int launch_regress_wino(RegressArgs a, int n, hipStream_t stream) {
             WinoArgs w;
             w.U = wsU; w.Wt = (const unsigned char *)a.reg[lvl].ww2; w.bn2s = a.reg[lvl].bn2s_w; w.bn2b = a.reg[lvl].bn2b;
             w.hinv = hinv; w.V = a.ws + (size_t)lvl * n * 512; w.mblocks = mblocks; w.p0 = p0; w.n = n;
+            w.dev_counts = a.dev_counts; w.nitems = a.nitems;
+            for (int b = 0; b <= MAXB; ++b) w.start[b] = a.start[b];
             hipLaunchKernelGGL(wino_gemm_kernel, dim3(((mblocks + 7) / 8) * 32), dim3(WNT), WLDS, stream, w);
             st = check_launch("wino_gemm_kernel");
             if (st != P2P_OK) return st;

@@ -47,7 +47,17 @@ class NcnWeights:
 
 # Experiments and the tile-independence tests: (mt, nt, wn) forced on every ConvBN launch (p2p_conv_set_tile); None = the
 # library picks by launch size.  The environment variable P2P_CONV_TILE="mt,nt,wn" sets it at import (tools).
-FORCED_CONV_TILE = tuple(int(v) for v in os.environ["P2P_CONV_TILE"].split(",")) if os.environ.get("P2P_CONV_TILE") else None
+def _parse_conv_tile(text):
+    try:
+        t = tuple(int(v) for v in text.split(","))
+    except ValueError:
+        t = ()
+    if len(t) != 3 or min(t) < 0:
+        raise ValueError(f"P2P_CONV_TILE={text!r}: expected three non-negative integers 'mt,nt,wn'")
+    return t
+
+
+FORCED_CONV_TILE = _parse_conv_tile(os.environ["P2P_CONV_TILE"]) if os.environ.get("P2P_CONV_TILE") else None
 
 
 class ConvBN:
@@ -182,12 +192,17 @@ class RegressorWeights:
             self.set_mode(env)
 
     def set_mode(self, mode):
-        """'fp16x2' (default: fp32-equivalent, two fp16 planes under exact power-of-two scales, 3 MFMA products), 'f32'
-        (exact fp32 MFMA) or 'fp16x2w' (fp16x2 with the second convolution as Winograd F(2x2,3x3) GEMMs).  The first selection of a
+        """'fp16x2w' (default: fp32-equivalent, two fp16 planes under exact power-of-two scales, 3 MFMA products, the second
+        convolution as Winograd F(2x2,3x3) GEMMs), 'fp16x2' (the same arithmetic, both convolutions direct, one launch) or 'f32'
+        (exact fp32 MFMA).  The first selection of a
         non-default mode packs and uploads that mode's weight stream (host work, ~1 s)."""
         if mode not in _lib.REGRESS_MODES:
-            raise ValueError(f"unknown regressor mode {mode!r}: one of {sorted(_lib.REGRESS_MODES)}")
-        _lib.check(_lib.p2p_regressor_set_mode(self.handle, _lib.REGRESS_MODES[mode]), "p2p_regressor_set_mode")
+            removed = {"bf16x2": "round 5", "bf16x3": "round 4"}
+            why = f" ({mode!r} was removed in {removed[mode]})" if mode in removed else ""
+            raise ValueError(f"unknown regressor mode {mode!r}{why}: one of {sorted(_lib.REGRESS_MODES)}")
+        # packing another mode's weight stream allocates and copies on the CURRENT device: make that the handle's device
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.p2p_regressor_set_mode(self.handle, _lib.REGRESS_MODES[mode]), "p2p_regressor_set_mode")
 
     @property
     def mode(self):

@@ -45,6 +45,8 @@ struct dim3 {
 
 struct uint2 { unsigned x, y; };
 static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 
 namespace hipemu {
 struct Idx { unsigned x, y, z; };
@@ -84,6 +86,7 @@ static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int
 static inline const char *hipGetErrorString(hipError_t) { return "hipemu"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
 template <class T> static inline hipError_t hipMalloc(T **p, size_t n) {
     *p = (T *)aligned_alloc(256, (n + 255) & ~size_t(255));

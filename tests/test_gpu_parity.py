@@ -35,7 +35,7 @@ def ops():
 
 
 MODES = ["fp16x2", "fp16x2w", "f32"]   # fp32-equivalent on two fp16 planes (direct conv2 | Winograd conv2), exact fp32 MFMA
-DEFAULT_MODE = "fp16x2"                         # include/p2p_hip.h: P2P_REGRESS_DEFAULT
+DEFAULT_MODE = "fp16x2w"                        # include/p2p_hip.h: P2P_REGRESS_DEFAULT
 
 
 @pytest.fixture(scope="module")

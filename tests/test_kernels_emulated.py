@@ -90,9 +90,9 @@ def test_coarse_batch_equals_single_pairs(emu, ncn):
             assert torch.equal(m[i], m1[0]) and torch.equal(s[i], s1[0])
 
 
-@pytest.mark.parametrize("mode", ["fp16x2", "f32"])
+@pytest.mark.parametrize("mode", ["fp16x2w", "fp16x2", "f32"])
 def test_regressors_against_reference_golden(mode, emu, sd):
-    """Both regressor kernels (split-bf16 and exact fp32 MFMA) on the first proposals of the reference's
+    """The regressor kernels (fp16x2 with Winograd / direct conv2, exact fp32 MFMA) on the first proposals of the reference's
     forward_fine_match golden: integer proposals through the mid regressor, float proposals through the fine one."""
     sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
     regs = {"int_mid": emu_lib.regressor_create(emu, sub("regress_mid."), mode),
@@ -138,7 +138,7 @@ torch.save((props, out), sys.argv[1])
     assert (out["matches1"] - ref_mid).abs().max() <= COORD_TOL and (out["probs1"] - ref_midp).abs().max() <= SCORE_TOL
 
 
-@pytest.mark.parametrize("mode", ["fp16x2"])
+@pytest.mark.parametrize("mode", ["fp16x2w", "fp16x2"])
 def test_regressor_chain_and_image_borders(mode, emu, sd):
     """Mid -> fine inside one launch (the fine patch is centred on the truncated mid match, its base is the
     un-truncated one), with proposals on the image corners where every level of the patch clamps."""

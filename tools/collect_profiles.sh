@@ -7,7 +7,7 @@
 set -u
 TAG=${1:-r02}
 shift || true
-MODES=${@:-fp16x2}
+MODES=${@:-fp16x2w}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT

@@ -12,8 +12,8 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
 if [ "$PART" = all ]; then
-  bash tools/collect_profiles.sh $TAG fp16x2 2>&1 | tail -6
-  P2P_CONFIG=E bash tools/collect_profiles.sh $TAG fp16x2 2>&1 | tail -6
+  bash tools/collect_profiles.sh $TAG fp16x2w 2>&1 | tail -6
+  P2P_CONFIG=E bash tools/collect_profiles.sh $TAG fp16x2w 2>&1 | tail -6
   cp $OUT/regress_traffic.json $ROOT/profiles/regress_traffic.json      # (on the box: the bench line below then carries the traffic)
   cd $ROOT; timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" 2>&1 | tail -2
   for B in 1 16; do BATCH=$B timeout 120 python tools/coarse_bench.py 2>&1 | tail -1; done > $OUT/${TAG}_coarse_bench.txt; H=960 W=1280 BATCH=2 REPS=10 timeout 120 python tools/coarse_bench.py 2>&1 | tail -1 >> $OUT/${TAG}_coarse_bench.txt; cat $OUT/${TAG}_coarse_bench.txt
@@ -31,8 +31,8 @@ elif [ "$PART" = part1 ]; then
   timeout 1500 python -m pytest tests -m gpu -x -q -s > $OUT/${TAG}_pytest.log 2>&1; tail -4 $OUT/${TAG}_pytest.log
   timeout 900 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; tail -c 1500 $OUT/${TAG}_bench.json; tail -3 $OUT/${TAG}_bench.err
 else
-  bash tools/collect_profiles.sh $TAG fp16x2 2>&1 | tail -12
-  P2P_CONFIG=E bash tools/collect_profiles.sh $TAG fp16x2 2>&1 | tail -12
+  bash tools/collect_profiles.sh $TAG fp16x2w 2>&1 | tail -12
+  P2P_CONFIG=E bash tools/collect_profiles.sh $TAG fp16x2w 2>&1 | tail -12
   timeout 300 python bench.py --pairs 2048 --no-e2e > $OUT/${TAG}_stream.json 2> $OUT/${TAG}_stream.err; tail -c 600 $OUT/${TAG}_stream.json
   timeout 300 python tools/backbone_bench.py > $OUT/${TAG}_backbone_bench.txt 2>&1; grep -v amdgpu.ids $OUT/${TAG}_backbone_bench.txt | tail -16
   timeout 300 python tools/conv_sweep.py > $OUT/${TAG}_conv_sweep.txt 2>&1; grep "x16" $OUT/${TAG}_conv_sweep.txt | cut -c1-200

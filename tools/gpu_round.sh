@@ -15,7 +15,7 @@ for w in $WHAT; do
     bench) timeout 600 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; tail -c 3000 $OUT/${TAG}_bench.json; tail -3 $OUT/${TAG}_bench.err;;
     benchE) timeout 900 python bench.py --config E --steps 6 --warmup 2 > $OUT/${TAG}_benchE.json 2> $OUT/${TAG}_benchE.err; tail -c 2500 $OUT/${TAG}_benchE.json; tail -3 $OUT/${TAG}_benchE.err;;
     check) timeout 600 python tools/split_check.py > $OUT/${TAG}_split_check.txt 2>&1; cat $OUT/${TAG}_split_check.txt;;
-    prof) bash tools/collect_profiles.sh $TAG fp16x2 f32;;
+    prof) bash tools/collect_profiles.sh $TAG fp16x2w f32;;
     prof3) bash tools/collect_profiles.sh $TAG fp16x2;;
   esac
 done

@@ -30,6 +30,8 @@ torch.cuda.synchronize()
 d = raw[5 * n:].view(64, 8, 16).cpu()
 names = ["gather", "scale+tab", "im2col", "level0+sync", "P (level 1)", "C (levels 2+3)", "fold", "conv1 end sync", "BN1+H write",
          "conv2 entry sync", "conv2 MFMA", "epilogue+sync", "-"]
+if MODE == "fp16x2w":
+    names[8], names[9], names[10] = "BN1 + H -> LDS", "transform + stores issued", "-"
 for grp, sl in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
     med = [d[:, sl, i].median().item() for i in range(13)]
     print(f"ticks per wave, median over 64 workgroups, {grp} (level 0, the middle proposal of the work-group's share):")
