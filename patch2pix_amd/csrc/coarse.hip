@@ -188,26 +188,30 @@ template <int KS>
 __global__ __launch_bounds__(256, 2) void corr_pool_kernel(const unsigned short *__restrict__ A, const unsigned short *__restrict__ B,
                                                            int nA, int nB, int C, float *__restrict__ P,
                                                            uint8_t *__restrict__ delta, size_t sAB, size_t sP, size_t sDelta,
-                                                           int gx, int gy, int ntiles) {
-    // work-group id -> (pair, A tile row, B tile column), see "Tile order" above
-    int rowA0, rowB0;
-    const unsigned char *Ab, *Bb;             // the tile's first blocks: stage it = block it of the row block
-    {
-        const int per = gridDim.x >> 3;
-        const int L = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-        if (L >= ntiles) return;
-        const int tp = gx * gy, z = L / tp, r = L - z * tp;
+                                                           int gx, int gy, int ntiles, int per_xcd) {
+    // Persistent work-groups: XCD x = blockIdx.x % 8 owns the tiles [x * per_xcd, (x + 1) * per_xcd) of the order described
+    // under "Tile order", its work-group j = blockIdx.x / 8 walks j, j + G, j + 2G, ... of them (G work-groups per XCD);
+    // stage 0 of the next tile is in flight during the pooling epilogue of the current one.
+    const int Gx = gridDim.x >> 3, xcd = blockIdx.x & 7;
+    int tj = blockIdx.x >> 3;
+    // tile number -> (pair, A tile row, B tile column)
+    int rowA0 = 0, rowB0 = 0, zp = 0;
+    const unsigned char *Ab = nullptr, *Bb = nullptr;             // the tile's first blocks: stage it = block it of the row block
+    auto locate = [&](int j, int &ra, int &rb, int &z, const unsigned char *&pa, const unsigned char *&pb) -> bool {
+        const int L = xcd * per_xcd + j;
+        if (j >= per_xcd || L >= ntiles) return false;
+        const int tp = gx * gy;
+        z = L / tp;
+        const int r = L - z * tp;
         const int blk = r / (CX_AB * gx), rr = r - blk * (CX_AB * gx);
         const int hb = min(CX_AB, gy - blk * CX_AB);
         const int bcol = rr / hb, arow = blk * CX_AB + rr - bcol * hb;
-        A += (size_t)z * sAB;
-        B += (size_t)z * sAB;
-        P += (size_t)z * sP;
-        if (delta) delta += (size_t)z * sDelta;
-        rowA0 = arow * CT; rowB0 = bcol * CT;
-        Ab = (const unsigned char *)A + (size_t)arow * (C >> 5) * CX_BLK;
-        Bb = (const unsigned char *)B + (size_t)bcol * (C >> 5) * CX_BLK;
-    }
+        ra = arow * CT; rb = bcol * CT;
+        pa = (const unsigned char *)(A + (size_t)z * sAB) + (size_t)arow * (C >> 5) * CX_BLK;
+        pb = (const unsigned char *)(B + (size_t)z * sAB) + (size_t)bcol * (C >> 5) * CX_BLK;
+        return true;
+    };
+    if (!locate(tj, rowA0, rowB0, zp, Ab, Bb)) return;
     P2P_DYN_SHARED(unsigned char, cx);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -219,6 +223,10 @@ __global__ __launch_bounds__(256, 2) void corr_pool_kernel(const unsigned short 
     const unsigned aoff0 = ((wr * 64 + l31) * 4 + ((0 + half) ^ sw)) * 16, aoff1 = ((wr * 64 + l31) * 4 + ((2 + half) ^ sw)) * 16;
     const unsigned boff0 = ((wc * 64 + l31) * 4 + ((0 + half) ^ sw)) * 16, boff1 = ((wc * 64 + l31) * 4 + ((2 + half) ^ sw)) * 16;
 
+    const int nk = C / 32;
+    CX_ISSUE(0, 0)
+#pragma unroll 1
+  for (;;) {
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -226,8 +234,6 @@ __global__ __launch_bounds__(256, 2) void corr_pool_kernel(const unsigned short 
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
 
     f32x4 xa[2][2], xb[2][2], ya[2][2], yb[2][2];
-    const int nk = C / 32;
-    CX_ISSUE(0, 0)
 #pragma unroll 1
     for (int it = 0; it < nk; it += 2) {
         // even stage (slot 0): its pieces have landed for everybody behind the barrier, and everybody is done with slot 1
@@ -256,6 +262,15 @@ __global__ __launch_bounds__(256, 2) void corr_pool_kernel(const unsigned short 
         CX_SLAB(ya, yb)
         __builtin_amdgcn_sched_barrier(0);
     }
+    // the next tile of this work-group: its stage 0 goes to slot 0 behind a barrier (everybody is done reading the ring)
+    const int rowA0c = rowA0, rowB0c = rowB0;
+    float *Pz = P + (size_t)zp * sP;
+    uint8_t *dz = delta ? delta + (size_t)zp * sDelta : nullptr;
+    tj += Gx;
+    const bool more = locate(tj, rowA0, rowB0, zp, Ab, Bb);
+    __builtin_amdgcn_s_barrier();
+    if (more) CX_ISSUE(0, 0)
+    __builtin_amdgcn_sched_barrier(0);
     // the planes carried 2^12 each: the accumulators hold 2^24 x the correlation (undone exactly at the stores; a maximum
     // commutes with the positive power of two)
     constexpr float inv = 1.0f / (CORR_FP16_SCALE * CORR_FP16_SCALE);
@@ -266,24 +281,23 @@ __global__ __launch_bounds__(256, 2) void corr_pool_kernel(const unsigned short 
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int tr = rowA0 + wr * 64 + i * 32, tc = rowB0 + wc * 64 + j * 32;
+                const int tr = rowA0c + wr * 64 + i * 32, tc = rowB0c + wc * 64 + j * 32;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = tr + (r & 3) + 8 * (r >> 2) + 4 * half, col = tc + l31;
-                    if (row < nA && col < nB) P[(size_t)row * nB + col] = acc[i][j][r] * inv;
+                    if (row < nA && col < nB) Pz[(size_t)row * nB + col] = acc[i][j][r] * inv;
                 }
             }
-        return;
-    }
+    } else
     // k = 2: a pooling cell is a 4x4 block: rows = (i,j) of A in regs 4g..4g+3, cols = (k,l) of B in 4 adjacent lanes.
     // First maximum in the order s = row_in_cell*4 + col_in_cell.  The exchange inside a quad of lanes is two DPP moves per
     // value (quad_perm; __shfl_xor goes through the LDS crossbar and is waited for: 64 of them were a third of a tile's
     // time), the pooled offsets are 32-bit (a pooled volume has < 2^31 cells), the bounds of a tile are checked once.
     {
         const int nAc = nA >> 2, nBc = nB >> 2;
-        const int crow0 = ((rowA0 + wr * 64) >> 2) + half, ccol0 = (rowB0 + wc * 64 + l31) >> 2;
+        const int crow0 = ((rowA0c + wr * 64) >> 2) + half, ccol0 = (rowB0c + wc * 64 + l31) >> 2;
         const bool writer = (lane & 3) == 0;
-        const bool full = ((rowA0 + CT) >> 2) <= nAc && ((rowB0 + CT) >> 2) <= nBc;      // (wave-uniform) no cell of the tile is outside
+        const bool full = ((rowA0c + CT) >> 2) <= nAc && ((rowB0c + CT) >> 2) <= nBc;      // (wave-uniform) no cell of the tile is outside
         // all sixteen cells of the lane's quad first (the exchanges need every lane), then ONE masked block of stores
         float pbest[2][2][4];
         int ps[2][2][4];
@@ -315,8 +329,8 @@ __global__ __launch_bounds__(256, 2) void corr_pool_kernel(const unsigned short 
                     ps[i][j][g] = s;
                 }
         if (writer) {
-            float *Pl = P + (unsigned)(crow0 * nBc + ccol0);
-            uint8_t *Dl = delta ? delta + (unsigned)(crow0 * nBc + ccol0) : nullptr;
+            float *Pl = Pz + (unsigned)(crow0 * nBc + ccol0);
+            uint8_t *Dl = dz ? dz + (unsigned)(crow0 * nBc + ccol0) : nullptr;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -332,6 +346,8 @@ __global__ __launch_bounds__(256, 2) void corr_pool_kernel(const unsigned short 
                     }
         }
     }
+    if (!more) break;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -691,13 +707,15 @@ extern "C" int p2p_coarse_forward_batch(const float *featA, const float *featB, 
             const int gx = ceil_div(nB, CT), gy = ceil_div(nA, CT);
             const long long ntiles = (long long)gx * gy * nz;
             P2P_REQUIRE(ntiles < (1ll << 30), P2P_EUNSUPPORTED, "p2p_coarse_forward: %lld correlation tiles in one launch", ntiles);
-            const dim3 cgrid((unsigned)(8 * ((ntiles + 7) / 8)));
+            // persistent work-groups: two fit a compute unit, 32 compute units per XCD
+            const int per_xcd = (int)((ntiles + 7) / 8);
+            const dim3 cgrid((unsigned)(8 * std::min(per_xcd, 64)));
             if (ksize == 1)
                 hipLaunchKernelGGL(corr_pool_kernel<1>, cgrid, dim3(256), CX_LDS, stream, fnA, fnB, nA, nB, C, P, (uint8_t *)nullptr,
-                                   2 * sWs, sWs, (size_t)0, gx, gy, (int)ntiles);
+                                   2 * sWs, sWs, (size_t)0, gx, gy, (int)ntiles, per_xcd);
             else
                 hipLaunchKernelGGL(corr_pool_kernel<2>, cgrid, dim3(256), CX_LDS, stream, fnA, fnB, nA, nB, C, P, dout, 2 * sWs, sWs,
-                                   nel, gx, gy, (int)ntiles);
+                                   nel, gx, gy, (int)ntiles, per_xcd);
         }
 
         const int col_groups = ceil_div(nBc, 256) * ceil_div(nAc, 64);

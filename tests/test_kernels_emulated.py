@@ -320,7 +320,7 @@ def test_device_filter_coarse_long_lists(n, distinct, emu):
     assert torch.equal(got[0][0], r) and torch.equal(got[0][1], rs)
 
 
-@pytest.mark.parametrize("mode", ["fp16x2"])
+@pytest.mark.parametrize("mode", ["fp16x2w", "fp16x2"])
 def test_regress_with_device_counts(mode, emu, sd):
     """p2p_regress_batch_dev: every item owns `stride` slots, the first counts[i] hold proposals; used slots equal the
     per-item call bit for bit, the others are not touched."""
