@@ -203,7 +203,9 @@ def parity_check(net, ckpt, batch, cpu_pairs, cfg, pairs=None):
     whole batch) and every pair of it (the first `pairs` of them) through the CPU oracle: coarse rows bit-exact?,
     sampled proposals equal?, regressed coordinates / scores max |diff|.  The fine level of the oracle is fed the
     kernel's own mid matches (a 1e-6 px wobble across an integer would move the whole fine patch by one pixel,
-    networks/utils.py:19); `max_px_err_fine_chain` is the plain end-to-end difference (pair 0).  The product samples the
+    networks/utils.py:19); `max_px_err_fine_chain` is the plain end-to-end difference over ALL checked pairs for the matches
+    whose truncated mid coordinates equal the oracle's, `fine_patches_moved_by_trunc` counts the others (their fine patch
+    sits one pixel off the oracle's; `max_px_err_fine_chain_moved` is their difference).  The product samples the
     ptmax proposals pair after pair from the global numpy RNG (networks/utils.py:55-63), the oracle from an equally
     seeded stream in the same order.  Where a coarse row differs from the fp32 oracle, the pair goes through the fp32
     error model of oracle/error_model.py: the row must be UNDECIDABLE in fp32 (the two candidates closer in an fp64
@@ -262,9 +264,18 @@ def parity_check(net, ckpt, batch, cpu_pairs, cfg, pairs=None):
             out["max_px_err"] = max(out["max_px_err"], float((fine[b].cpu() - r_fine).abs().max()))
             out["max_score_err"] = max(out["max_score_err"], float((mid_s[b].cpu() - r_ms).abs().max()),
                                        float((fine_s[b].cpu() - r_fs).abs().max()))
-            if b == 0:
-                chain, _, _ = orc.fine_level(p1[:4], p2[:4], r_mid, fine_p)
-                out["max_px_err_fine_chain"] = float((fine[0].cpu() - chain).abs().max())
+            # the plain chain: the oracle's fine level on the ORACLE's mid matches.  A mid coordinate within the rounding
+            # error of an integer truncates differently (networks/utils.py:19) and moves that match's whole fine patch by
+            # one pixel: such matches are counted, the others compared
+            chain, _, _ = orc.fine_level(p1[:4], p2[:4], r_mid, fine_p)
+            moved = (g_mid.long() != r_mid.long()).any(dim=1)
+            out["fine_patches_moved_by_trunc"] = out.get("fine_patches_moved_by_trunc", 0) + int(moved.sum())
+            if bool((~moved).any()):
+                out["max_px_err_fine_chain"] = max(out.get("max_px_err_fine_chain", 0.0),
+                                                   float((fine[b].cpu() - chain)[~moved].abs().max()))
+            if bool(moved.any()):
+                out["max_px_err_fine_chain_moved"] = max(out.get("max_px_err_fine_chain_moved", 0.0),
+                                                         float((fine[b].cpu() - chain)[moved].abs().max()))
     out["coarse_indices_equal"] = out["coarse_rows_differing_decidable"] == 0
     out["proposals_equal"] = out["pairs_with_equal_proposals"] == B
     out.update({"tolerance_px": 1e-3, "tolerance_score": 1e-5})

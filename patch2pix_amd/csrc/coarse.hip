@@ -502,20 +502,22 @@ __device__ __forceinline__ void emit_match(const MatchArgs &m, int out_row, int 
     m.scores[out_row] = 1.0f / sum_exp;       // max of softmax = exp(0) / sum exp(x - max)
 }
 
-// direction B->A: one block per 8 columns, 32 interleaved row slices
+// direction B->A: one block per 32 columns (a row of the block = one 128-byte line: 8-column blocks fetched every line of
+// the volume four times), 8 interleaved row slices
+constexpr int MC_COLS = 32, MC_SLICES = 8;
 __global__ __launch_bounds__(256) void match_cols_kernel(MatchArgs m_) {
     const MatchArgs m = match_args_of_pair(m_, blockIdx.z);
-    __shared__ float smax[32][8];
-    __shared__ int sarg[32][8];
-    __shared__ float ssum[32][8];
+    __shared__ float smax[MC_SLICES][MC_COLS];
+    __shared__ int sarg[MC_SLICES][MC_COLS];
+    __shared__ float ssum[MC_SLICES][MC_COLS];
     const int nA = m.hA * m.wA, nB = m.hB * m.wB;
-    const int cs = threadIdx.x & 7, rs = threadIdx.x >> 3;
-    const int col = blockIdx.x * 8 + cs;
+    const int cs = threadIdx.x & (MC_COLS - 1), rs = threadIdx.x / MC_COLS;
+    const int col = blockIdx.x * MC_COLS + cs;
     const bool ok = col < nB;
     float best = -INFINITY;
     int arg = 0x7fffffff;
     if (ok)
-        for (int r = rs; r < nA; r += 32) {
+        for (int r = rs; r < nA; r += MC_SLICES) {
             const float v = m.X[(size_t)r * nB + col];
             if (v > best) { best = v; arg = r; }
         }
@@ -524,20 +526,20 @@ __global__ __launch_bounds__(256) void match_cols_kernel(MatchArgs m_) {
     float gb = smax[0][cs];
     int ga = sarg[0][cs];
 #pragma unroll
-    for (int s = 1; s < 32; ++s) {
+    for (int s = 1; s < MC_SLICES; ++s) {
         const float v = smax[s][cs];
         const int a = sarg[s][cs];
         if (v > gb || (v == gb && a < ga)) { gb = v; ga = a; }
     }
     float sum = 0.f;
     if (ok)
-        for (int r = rs; r < nA; r += 32) sum += expf(m.X[(size_t)r * nB + col] - gb);
+        for (int r = rs; r < nA; r += MC_SLICES) sum += expf(m.X[(size_t)r * nB + col] - gb);
     ssum[rs][cs] = sum;
     __syncthreads();
     if (rs == 0 && ok) {
         float t = 0.f;
 #pragma unroll
-        for (int s = 0; s < 32; ++s) t += ssum[s][cs];
+        for (int s = 0; s < MC_SLICES; ++s) t += ssum[s][cs];
         emit_match(m, col, ga, col, t);
     }
 }
@@ -775,7 +777,7 @@ extern "C" int p2p_coarse_matches_batch(const float *corr4d, const uint8_t *delt
     const int nA = hA * wA, nB = hB * wB;
     MatchArgs m{corr4d, delta, hA, wA, hB, wB, ksize, upsample, center, (long long *)matches_out, scores_out,
                 (size_t)nA * nB, (size_t)nA + nB};
-    hipLaunchKernelGGL(match_cols_kernel, dim3(ceil_div(nB, 8), 1, batch), dim3(256), 0, (hipStream_t)stream, m);
+    hipLaunchKernelGGL(match_cols_kernel, dim3(ceil_div(nB, MC_COLS), 1, batch), dim3(256), 0, (hipStream_t)stream, m);
     hipLaunchKernelGGL(match_rows_kernel, dim3(ceil_div(nA, 4), 1, batch), dim3(256), 0, (hipStream_t)stream, m);
     return check_launch("match kernels");
 }
