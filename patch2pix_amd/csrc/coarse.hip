@@ -502,9 +502,9 @@ __device__ __forceinline__ void emit_match(const MatchArgs &m, int out_row, int 
     m.scores[out_row] = 1.0f / sum_exp;       // max of softmax = exp(0) / sum exp(x - max)
 }
 
-// direction B->A: one block per 32 columns (a row of the block = one 128-byte line: 8-column blocks fetched every line of
-// the volume four times), 8 interleaved row slices
-constexpr int MC_COLS = 32, MC_SLICES = 8;
+// direction B->A: one block per 16 columns (a row of the block = half a 128-byte line: 8-column blocks fetched every line of
+// the volume four times; 32 columns leave too few blocks per pair), 16 interleaved row slices
+constexpr int MC_COLS = 16, MC_SLICES = 16;
 __global__ __launch_bounds__(256) void match_cols_kernel(MatchArgs m_) {
     const MatchArgs m = match_args_of_pair(m_, blockIdx.z);
     __shared__ float smax[MC_SLICES][MC_COLS];

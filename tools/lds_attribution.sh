@@ -8,9 +8,9 @@ export NPROP=6400 NPAIRS=16
 for v in default skipconv2 skipc skipp skipfold pinw; do
   lib=$ROOT/tools/exp/lib_$v.so; [ $v = default ] && lib=$ROOT/patch2pix_amd/csrc/libp2p_hip.so
   echo "== $v"
-  P2P_LIB_PATH=$lib NITER=7 timeout 120 python $ROOT/tools/regress_bench.py fp16x2 2>&1 | grep median
+  P2P_ALLOW_EXPERIMENT=1 P2P_LIB_PATH=$lib NITER=7 timeout 120 python $ROOT/tools/regress_bench.py fp16x2 2>&1 | grep median
   rm -rf /tmp/pl
-  P2P_LIB_PATH=$lib NITER=2 timeout 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_LDS_ADDR_CONFLICT --kernel-trace -d /tmp/pl -o r -- python $ROOT/tools/regress_bench.py fp16x2 > /dev/null 2>&1
+  P2P_ALLOW_EXPERIMENT=1 P2P_LIB_PATH=$lib NITER=2 timeout 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_LDS_ADDR_CONFLICT --kernel-trace -d /tmp/pl -o r -- python $ROOT/tools/regress_bench.py fp16x2 > /dev/null 2>&1
   python - <<PY
 import sqlite3, glob
 db = glob.glob("/tmp/pl/**/*.db", recursive=True)

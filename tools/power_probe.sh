@@ -8,8 +8,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
 export NPROP=6400 NPAIRS=16 NITER=9
 echo "== 256 CUs"; timeout 200 python tools/regress_bench.py fp16x2 2>&1 | grep median
-echo "== 128 CUs"; P2P_LIB_PATH=$ROOT/tools/exp/lib_cap128.so timeout 200 python tools/regress_bench.py fp16x2 2>&1 | grep median
-echo "== 64 CUs";  P2P_LIB_PATH=$ROOT/tools/exp/lib_cap64.so timeout 200 python tools/regress_bench.py fp16x2 2>&1 | grep median
+echo "== 128 CUs"; P2P_ALLOW_EXPERIMENT=1 P2P_LIB_PATH=$ROOT/tools/exp/lib_cap128.so timeout 200 python tools/regress_bench.py fp16x2 2>&1 | grep median
+echo "== 64 CUs";  P2P_ALLOW_EXPERIMENT=1 P2P_LIB_PATH=$ROOT/tools/exp/lib_cap64.so timeout 200 python tools/regress_bench.py fp16x2 2>&1 | grep median
 echo "== 256 CUs, zero weights"; ZERO_W=1 timeout 200 python tools/regress_bench.py fp16x2 2>&1 | grep median
 echo "== 256 CUs, exact f32 kernel (for the clock comparison)"; NITER=3 timeout 200 python tools/regress_bench.py f32 2>&1 | grep median
 echo "== rocm-smi while the fp16x2 launch repeats"

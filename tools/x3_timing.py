@@ -1,4 +1,4 @@
-"""Phase cycle counts of the fp16x2 regress kernel (needs the -DP2P_X3_TIMING build, P2P_LIB_PATH=tools/exp/lib_timing.so)."""
+"""Phase cycle counts of the fp16x2 regress kernel (needs the -DP2P_X3_TIMING build: P2P_ALLOW_EXPERIMENT=1 P2P_LIB_PATH=tools/exp/lib_timing.so; MODE=fp16x2w for the conv1 launch of the Winograd path)."""
 import sys, os; sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import ctypes, torch
 from patch2pix_amd import ops, _lib
