@@ -295,6 +295,12 @@ def roofline_of(mode, events):
            "peak_note": M["peak_note"],
            "note": "achieved = algorithmic flop of the launch (608.3 MFLOP x proposals x levels) / launch time "
                    "measured with HIP events on the launch stream"}
+    if M["products"]:
+        out["power_ceiling_note"] = ("the nominal peak is not reachable on random data under the 1400 W package limit: a register-only "
+                                     "v_mfma_f32_32x32x16_f16 loop measures 1.69 PFLOP/s (0.68 of 2.5; zeros: 2.49) = 563 TFLOP/s in "
+                                     "three-product fp32-equivalent terms, and kernels that also move their operands sit at "
+                                     "1.0-1.1 GHz of matrix-pipe issue against its 1.61 (profiles/r05_mfma_power_ceiling.txt, "
+                                     "DESIGN.md section 4)")
     if "kernels" in M:
         out["kernels"] = M["kernels"]
         out["note"] = ("the fine stage of one step = ONE p2p_regress_batch call = per regressor level and chunk of 2048 proposals "
