@@ -94,6 +94,7 @@ p2p_regress = _sig("p2p_regress", ctypes.c_int,
                    [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Pyramid), ctypes.POINTER(Pyramid),
                     ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.c_void_p, ctypes.c_size_t, c_stream])
 p2p_regress_workspace_bytes = _sig("p2p_regress_workspace_bytes", ctypes.c_size_t, [ctypes.c_int])
+p2p_regress_workspace_bytes_mode = _sig("p2p_regress_workspace_bytes_mode", ctypes.c_size_t, [ctypes.c_int, ctypes.c_int])
 
 p2p_regress_batch = _sig("p2p_regress_batch", ctypes.c_int,
                          [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(Pyramid), ctypes.POINTER(Pyramid),
@@ -125,7 +126,7 @@ REGRESS_MODES = {"f32": 0, "fp16x2": 3, "fp16x2w": 4}
 
 EXPORTS = ["p2p_version", "p2p_last_error", "p2p_ncn_create", "p2p_ncn_destroy", "p2p_ncn_set_tile", "p2p_regressor_create",
            "p2p_regressor_destroy", "p2p_coarse_workspace_bytes", "p2p_coarse_forward", "p2p_coarse_forward_batch",
-           "p2p_neigh_consensus_batch", "p2p_delta_unpack", "p2p_coarse_matches", "p2p_coarse_matches_batch", "p2p_filter_coarse_workspace_bytes", "p2p_filter_coarse_batch", "p2p_match_tail_batch", "p2p_regress", "p2p_regress_workspace_bytes", "p2p_regress_batch", "p2p_regress_batch_dev", "p2p_regressor_set_mode",
+           "p2p_neigh_consensus_batch", "p2p_delta_unpack", "p2p_coarse_matches", "p2p_coarse_matches_batch", "p2p_filter_coarse_workspace_bytes", "p2p_filter_coarse_batch", "p2p_match_tail_batch", "p2p_regress", "p2p_regress_workspace_bytes", "p2p_regress_workspace_bytes_mode", "p2p_regress_batch", "p2p_regress_batch_dev", "p2p_regressor_set_mode",
            "p2p_regressor_get_mode", "p2p_conv_create", "p2p_conv_destroy", "p2p_conv_set_tile", "p2p_conv_forward", "p2p_absmax_batch", "p2p_stem_create", "p2p_stem_destroy", "p2p_stem_forward",
            "p2p_maxpool_nhwc", "p2p_nhwc_to_nchw"]
 

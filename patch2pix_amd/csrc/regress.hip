@@ -561,9 +561,12 @@ static int regress_batch_impl(const p2p_regressor *reg1, const p2p_regressor *re
             for (int b = i0; b < nitems && b < i0 + MAXB; ++b) n += counts[b];
             most = std::max(most, n);
         }
-        P2P_REQUIRE(workspace && workspace_bytes >= regress_ws_floats((size_t)most) * sizeof(float) && ((uintptr_t)workspace & 127) == 0,
+        // the direct mode only parks the pooled features and the next level's proposals; the Winograd mode also the
+        // transformed conv2 input of a chunk (p2p_regress_workspace_bytes_mode)
+        const size_t need = (reg1->mode == P2P_REGRESS_FP16X2W ? regress_ws_floats((size_t)most) : regress_ws_base_floats((size_t)most)) * sizeof(float);
+        P2P_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace & 127) == 0,
                     P2P_EINVAL, "p2p_regress: workspace of %zu bytes (p2p_regress_workspace_bytes, 128-byte aligned) needed, got %zu",
-                    regress_ws_floats((size_t)most) * sizeof(float), workspace ? workspace_bytes : (size_t)0);
+                    need, workspace ? workspace_bytes : (size_t)0);
     }
     int dev = 0;
     P2P_HIP_CHECK(hipGetDevice(&dev));
@@ -632,6 +635,11 @@ extern "C" int p2p_regress_batch(const p2p_regressor *reg1, const p2p_regressor 
 
 extern "C" size_t p2p_regress_workspace_bytes(int n) {
     return n > 0 ? regress_ws_floats((size_t)n) * sizeof(float) : 0;
+}
+
+extern "C" size_t p2p_regress_workspace_bytes_mode(int n, int mode) {
+    if (n <= 0 || mode == P2P_REGRESS_F32) return 0;
+    return (mode == P2P_REGRESS_FP16X2W ? regress_ws_floats((size_t)n) : regress_ws_base_floats((size_t)n)) * sizeof(float);
 }
 
 extern "C" int p2p_regress_batch_dev(const p2p_regressor *reg1, const p2p_regressor *reg2, int nitems,

@@ -448,7 +448,7 @@ def regress_batch_dev(reg1, reg2, pyrs1, pyrs2, proposals, counts, want_raw=Fals
     g = lambda k: out[k].data_ptr() if k in out else None
     if nb and stride:
         with torch.cuda.device(dev):
-            ws = _regress_scratch(dev, nb * stride)
+            ws = _regress_scratch(dev, nb * stride, reg1)
             _lib.check(_lib.p2p_regress_batch_dev(reg1.handle, reg2.handle if two else None, nb, pyr_a, pyr_b,
                                                   counts.data_ptr(), stride, proposals.data_ptr(),
                                                   int(proposals.is_floating_point()), g("matches1"), g("probs1"), g("raw1"),
@@ -458,10 +458,15 @@ def regress_batch_dev(reg1, reg2, pyrs1, pyrs2, proposals, counts, want_raw=Fals
     return out
 
 
-def _regress_scratch(dev, n):
-    """Scratch of one regress launch (the pooled convolution features wait there for the batched FC tail): a fresh
-    stream-ordered allocation per call, so that launches on different streams never share it."""
-    return torch.empty(_lib.p2p_regress_workspace_bytes(int(n)), dtype=torch.uint8, device=dev)
+def _regress_scratch(dev, n, reg=None):
+    """Scratch of one regress call (the pooled convolution features wait there for the batched FC tail; in the default mode
+    also the Winograd-transformed input of the second convolution, chunk by chunk): a fresh stream-ordered allocation per
+    call, so that calls on different streams never share it; sized for the regressor's arithmetic mode."""
+    if reg is None:
+        nbytes = _lib.p2p_regress_workspace_bytes(int(n))
+    else:
+        nbytes = _lib.p2p_regress_workspace_bytes_mode(int(n), _lib.p2p_regressor_get_mode(reg.handle))
+    return torch.empty(max(int(nbytes), 128), dtype=torch.uint8, device=dev)
 
 
 def _pyramid(levels):
@@ -531,7 +536,7 @@ def regress_batch(reg1, reg2, pyrs1, pyrs2, proposals, want_mid=True, want_raw=F
     r2 = buf("raw2", 5, two and want_raw)
     if n:
         with torch.cuda.device(dev):
-            ws = _regress_scratch(dev, n)
+            ws = _regress_scratch(dev, n, reg1)
             ev = None
             if regress_events is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

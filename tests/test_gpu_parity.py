@@ -269,6 +269,42 @@ def test_fine_empty_and_single(dev, ops, weights):
     assert out["matches2"].shape == (1, 4) and torch.isfinite(out["matches2"]).all()
 
 
+def test_regress_workspace_is_sized_per_mode(dev, ops, weights):
+    """p2p_regress_workspace_bytes_mode: the direct fp16x2 mode parks 4 KB per proposal, the Winograd mode also the
+    transformed conv2 input of a chunk; a buffer that is too small for the handle's mode is P2P_EINVAL, never a fault."""
+    import ctypes
+    from patch2pix_amd import _lib
+    _, _, mid_w, fine_w = weights
+    n = 40
+    mode = _lib.REGRESS_MODES[mid_w.mode]
+    need = _lib.p2p_regress_workspace_bytes_mode(n, mode)
+    assert need <= _lib.p2p_regress_workspace_bytes(n)
+    if mid_w.mode == "f32":
+        assert need == 0
+        return
+    assert _lib.p2p_regress_workspace_bytes_mode(n, _lib.REGRESS_MODES["fp16x2"]) < 1 << 20 < _lib.p2p_regress_workspace_bytes_mode(n, _lib.REGRESS_MODES["fp16x2w"])
+    p1 = _gpu(synthetic.make_pyramid(1, 48, 64)[:4], dev)
+    p2 = _gpu(synthetic.make_pyramid(2, 48, 64)[:4], dev)
+    pa, ka = ops._pyramid(p1)
+    pb, kb = ops._pyramid(p2)
+    props = torch.randint(0, 48, (n, 4), device=dev)
+    m1, q1 = torch.empty((n, 4), device=dev), torch.empty((n,), device=dev)
+    m2, q2 = torch.empty((n, 4), device=dev), torch.empty((n,), device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def call(nbytes):
+        ws = torch.empty(max(nbytes, 128), dtype=torch.uint8, device=dev)
+        return _lib.p2p_regress(mid_w.handle, fine_w.handle, ctypes.byref(pa), ctypes.byref(pb), props.data_ptr(), 0, n,
+                                m1.data_ptr(), q1.data_ptr(), None, m2.data_ptr(), q2.data_ptr(), None, ws.data_ptr(), nbytes, stream)
+    assert call(need) == 0
+    torch.cuda.synchronize()
+    want = m2.clone()
+    assert call(need - 256) == -1 and b"workspace" in _lib.p2p_last_error()
+    assert call(_lib.p2p_regress_workspace_bytes(n)) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(m2, want)
+
+
 # ------------------------------------------------------------------------------------------ whole path
 def _model(dev, contrast=None):
     from patch2pix_amd.utils.eval import model_helper
