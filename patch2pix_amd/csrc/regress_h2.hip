@@ -379,6 +379,80 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
 #pragma unroll 1
     for (int lvl = WINO ? args.lvl0 : 0; lvl < (WINO ? args.lvl0 + 1 : args.nlevels); ++lvl) {
         const RegDev &R_ = args.reg[lvl];
+        // WINO: the gather of proposal i + 1 is issued before the transform + write-out of proposal i (its ~40 scattered loads
+        // per thread land in these registers while that phase runs) and committed to LDS at the top of its own iteration
+        float gn0[2][2], gn1[2][11], gn2[2][4], gn3[2][3];
+        bool pre = false;                    // gn* hold the gather of the proposal the next iteration starts with
+        auto gather_loads = [&](int xa_, int ya_, int xb_, int yb_, const ItemDev &J) {
+            int tv = wave * 64 + P2P_LANE_ID();
+            P2P_OPAQUE(tv);
+#pragma unroll
+            for (int img = 0; img < 2; ++img) {
+                const int Hh = J.H[img], Ww = J.W[img], x0 = img ? xb_ : xa_, y0 = img ? yb_ : ya_;
+                {
+                    const int r0 = clampi(y0, 0, Hh - 1), c0 = clampi(x0, 0, Ww - 1);
+                    const float *src = J.pyr[img][0];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int e = tv + k * NT;
+                        const int c = e >> 8, rem = e & 255, r = rem >> 4, cc = rem & 15;
+                        gn0[img][k] = (e < 768) ? src[((size_t)c * Hh + min(r0 + r, Hh - 1)) * Ww + min(c0 + cc, Ww - 1)] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int j = 1; j < 4; ++j) {
+                    const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
+                    const int Cc = (j == 3) ? 128 : 64;
+                    const int nk = (j == 1) ? 11 : (j == 2) ? 4 : 3;
+                    const int Hj = Hh >> j, Wj = Ww >> j;
+                    const int Ha = level_dim(Hh, j), Wa = level_dim(Ww, j);
+                    const int r0 = clampi(y0 >> j, 0, Hj - 1);
+                    const int c0 = clampi(x0 >> j, 0, Wj - 1);
+                    const float *src = J.pyr[img][j];
+#pragma unroll
+                    for (int k = 0; k < nk; ++k) {
+                        const int e = tv + k * NT;
+                        const int c = e / (Rr * Rr);
+                        const int rem = e - c * (Rr * Rr);
+                        const int r = rem / Rr;
+                        const int cc = rem - r * Rr;
+                        const float v = (e < Cc * Rr * Rr)
+                                            ? src[((size_t)c * Ha + min(r0 + r, Hj - 1)) * Wa + min(c0 + cc, Wj - 1)] : 0.f;
+                        if (j == 1) gn1[img][k] = v; else if (j == 2) gn2[img][k] = v; else gn3[img][k] = v;
+                    }
+                }
+            }
+        };
+        auto gather_commit = [&]() {
+            int tv = wave * 64 + P2P_LANE_ID();
+            P2P_OPAQUE(tv);
+#pragma unroll
+            for (int img = 0; img < 2; ++img) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int e = tv + k * NT;
+                    if (e < 768) raw0[img * 768 + e] = gn0[img][k];
+                }
+                unsigned char *tb = smb + img * XIMG;
+#pragma unroll
+                for (int j = 1; j < 4; ++j) {
+                    const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
+                    const int Cc = (j == 3) ? 128 : 64;
+                    const int nk = (j == 1) ? 11 : (j == 2) ? 4 : 3;
+#pragma unroll
+                    for (int k = 0; k < nk; ++k) {
+                        const int e = tv + k * NT;
+                        if (e < Cc * Rr * Rr) {
+                            const int c = e / (Rr * Rr);
+                            const int rem = e - c * (Rr * Rr);
+                            const float v = (j == 1) ? gn1[img][k] : (j == 2) ? gn2[img][k] : gn3[img][k];
+                            if (j == 1) *(float *)(tb + XOFF1 + (rem / 9) * XRP1 + (rem % 9) * XST1 + c * 4) = v;
+                            else *(float *)(smb + XSHARED + img * XTMPIMG + ((j == 2) ? rem * XTMP2ST : XTMP3 + rem * XTMP3ST) + c * 4) = v;
+                        }
+                    }
+                }
+            }
+        };
 #pragma unroll 1
       for (int cprop = (WINO ? args.p0 : 0) + blockIdx.x; cprop < (WINO ? args.p1 : args.n); cprop += nwg) {
         // WINO: cprop is the compact index of a proposal that exists (its scratch rows), prop its slot; else they coincide
@@ -388,19 +462,35 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
         while (it + 1 < args.nitems && prop >= args.start[it + 1]) ++it;
         if (!WINO && args.dev_counts && prop - args.start[it] >= args.dev_counts[it]) continue;      // empty slot (whole work-group)
         const ItemDev &I = args.item[it];
-        if (tid < 4) {
+        int tq = tid;                        // WINO: an opaque copy -- the lane's load addresses are otherwise hoisted out of the loop and spilled
+        if constexpr (WINO) {
+            tq = wave * 64 + P2P_LANE_ID();
+            P2P_OPAQUE(tq);
+        }
+        if (tq < 4) {
             float v;
-            if (lvl > 0) v = load_coherent(XWS_NEXTP() + (size_t)prop * 4 + tid);
-            else if (args.is_float) v = ((const float *)args.proposals)[(size_t)prop * 4 + tid];
-            else v = (float)((const long long *)args.proposals)[(size_t)prop * 4 + tid];
+            if (lvl > 0) v = load_coherent(XWS_NEXTP() + (size_t)prop * 4 + tq);
+            else if (args.is_float) v = ((const float *)args.proposals)[(size_t)prop * 4 + tq];
+            else v = (float)((const long long *)args.proposals)[(size_t)prop * 4 + tq];
 #ifdef XF_SAME_PATCH                    // timing experiment (wrong results): every proposal gathers the same (cache-resident) patch
-            v = 100.f + 16.f * tid;
+            v = 100.f + 16.f * tq;
 #endif
-            misc[8 + tid] = v;
+            misc[8 + tq] = v;
+        }
+        if constexpr (WINO) {                // the proposal this work-group takes next (its gather is prefetched): coordinates -> misc[4..7]
+            const int nprop = (cprop + nwg < args.p1) ? wino_slot(args, cprop + nwg) : -1;
+            if (nprop >= 0 && tq >= 4 && tq < 8) {
+                const int q = tq - 4;
+                float v;
+                if (lvl > 0) v = load_coherent(XWS_NEXTP() + (size_t)nprop * 4 + q);
+                else if (args.is_float) v = ((const float *)args.proposals)[(size_t)nprop * 4 + q];
+                else v = (float)((const long long *)args.proposals)[(size_t)nprop * 4 + q];
+                misc[4 + q] = v;
+            }
         }
         // per-level reductions behind the power-of-two operand scales: misc[12 + img] = smallest per-pixel L2 scale of the
         // image (float bits, atomic min), misc[14] = largest |H| (float bits, atomic max)
-        if (tid >= 64 && tid < 67) ((int *)misc)[12 + tid - 64] = (tid < 66) ? 0x7f7fffff : 0;
+        if (tq >= 64 && tq < 67) ((int *)misc)[12 + tq - 64] = (tq < 66) ? 0x7f7fffff : 0;
         __syncthreads();
         // window origins (x, y) in image 1 / image 2 (networks/utils.py:8-19); scalars + selects, never an indexed array
         int moff = 8;                // opaque: the LDS address of misc is otherwise materialised before the loop and spilled
@@ -421,7 +511,10 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
         if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 
         // ------------------------------------------------------------ gather (networks/utils.py:4-36)
-        {
+        if constexpr (WINO) {
+            if (!pre) gather_loads(xa, ya, xb, yb, I);       // the work-group's first proposal: nothing was prefetched
+            gather_commit();
+        } else {
             // two passes so that all ~40 scattered 4-byte loads of a thread are in flight together
             float g0[2][2], g1[2][11], g2[2][4], g3[2][3];
 #pragma unroll
@@ -801,10 +894,39 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
             }
             __syncthreads();
             XT(8)
+            // the next proposal's gather: in flight during the transform and the write-out below (its slot is looked up again:
+            // one value less alive across conv1)
+            const int nprop2 = (cprop + nwg < args.p1) ? wino_slot(args, cprop + nwg) : -1;
+            pre = nprop2 >= 0;
+            if (pre) {
+                int nit = 0;
+                while (nit + 1 < args.nitems && nprop2 >= args.start[nit + 1]) ++nit;
+                int mo2 = 4;
+                P2P_OPAQUE(mo2);
+                gather_loads((int)misc[mo2 + 0] - 8, (int)misc[mo2 + 1] - 8, (int)misc[mo2 + 2] - 8, (int)misc[mo2 + 3] - 8, args.item[nit]);
+            } else {
+                // (defined on this path too: otherwise the values committed at the top of this iteration count as live across
+                // conv1 -- the compiler does not see that `pre == false` makes the next iteration reload them -- 40 registers)
+                float zf = 0.f;
+                P2P_OPAQUE(zf);
+#pragma unroll
+                for (int im = 0; im < 2; ++im) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) gn0[im][k] = zf;
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) gn1[im][k] = zf;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) gn2[im][k] = zf;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) gn3[im][k] = zf;
+                }
+            }
             // item = K chunk of 32 channels: lane = (tile, 8 channels), two passes of 4 channels; a lane's 8 values of a
             // (position, plane) are ONE 16-byte store and a wave's store covers the proposal's 16 rows of a block = 1 KiB
             // contiguous (8-byte stores in 64-byte runs cost 2 ms of a 14.5 ms launch in write bandwidth)
-            const int lq = tidv & 63, oct = lq & 3, tile = lq >> 2, ty = tile >> 2, tx = tile & 3;
+            int tve = P2P_LANE_ID();             // a fresh opaque lane id: values derived from the loop's tidv would be kept across conv1
+            P2P_OPAQUE(tve);
+            const int lq = tve & 63, oct = lq & 3, tile = lq >> 2, ty = tile >> 2, tx = tile & 3;
             const unsigned pl = (unsigned)(cprop - args.p0);
 #ifdef XF_WINO_NOSTORE                   // timing experiment (wrong results): every store of the transform lands in one 32 KB window
             const unsigned pstride = 0;
@@ -813,14 +935,12 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
 #endif
             const unsigned rr = (pl & 7u) * 16u + (unsigned)tile;
             const unsigned inblk = (rr * 4u + ((unsigned)oct ^ ((rr >> 2) & 3u))) * 16u;
-            int pxo[4][4];                                        // LDS offsets of the window (outside the map: the zero row)
-#pragma unroll
-            for (int aa = 0; aa < 4; ++aa)
-#pragma unroll
-                for (int bb = 0; bb < 4; ++bb) {
-                    const int y = 2 * ty + aa - 1, x = 2 * tx + bb - 1;
-                    pxo[aa][bb] = (((unsigned)y < 8u && (unsigned)x < 8u) ? y * 8 + x : 64) * HWST + oct * 32;
-                }
+            // LDS offset of window element (aa, bb) (outside the map: the zero row); recomputed where it is used -- a table of the 16
+            // offsets would be 16 more live registers beside the window, the first pass's planes and the prefetched gather
+            auto pxo = [&](int aa, int bb) {
+                const int y = 2 * ty + aa - 1, x = 2 * tx + bb - 1;
+                return (((unsigned)y < 8u && (unsigned)x < 8u) ? y * 8 + x : 64) * HWST + oct * 32;
+            };
 #ifdef XF_WINO_NOXF                      // timing experiments (wrong results): no transform pass / no stores of its results
             if (args.n < 0)
 #endif
@@ -839,22 +959,21 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
 #pragma unroll
                     for (int aa = 0; aa < 4; ++aa)
 #pragma unroll
-                        for (int bb = 0; bb < 4; ++bb) d[aa][bb] = *(const f32x4 *)(smb + pxo[aa][bb] + kc * 128 + hh * 16);
-                    // B^T d B,  B^T = [[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]]
-                    f32x4 tr[4][4];
+                        for (int bb = 0; bb < 4; ++bb) d[aa][bb] = *(const f32x4 *)(smb + pxo(aa, bb) + kc * 128 + hh * 16);
+                    // B^T d B,  B^T = [[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]]; one row of B^T d at a time
+                    // (the whole 4 x 4 intermediate beside the window, the first pass's planes and the prefetched gather of
+                    // the next proposal does not fit 256 registers)
 #pragma unroll
-                    for (int bb = 0; bb < 4; ++bb) {
-                        tr[0][bb] = d[0][bb] - d[2][bb];
-                        tr[1][bb] = d[1][bb] + d[2][bb];
-                        tr[2][bb] = d[2][bb] - d[1][bb];
-                        tr[3][bb] = d[1][bb] - d[3][bb];
-                    }
+                    for (int ii = 0; ii < 4; ++ii) {
+                        f32x4 tr[4];
 #pragma unroll
-                    for (int ii = 0; ii < 4; ++ii)
+                        for (int bb = 0; bb < 4; ++bb)
+                            tr[bb] = (ii == 0) ? d[0][bb] - d[2][bb] : (ii == 1) ? d[1][bb] + d[2][bb]
+                                   : (ii == 2) ? d[2][bb] - d[1][bb] : d[1][bb] - d[3][bb];
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) {
-                            const f32x4 v = (jj == 0) ? tr[ii][0] - tr[ii][2] : (jj == 1) ? tr[ii][1] + tr[ii][2]
-                                          : (jj == 2) ? tr[ii][2] - tr[ii][1] : tr[ii][1] - tr[ii][3];
+                            const f32x4 v = (jj == 0) ? tr[0] - tr[2] : (jj == 1) ? tr[1] + tr[2]
+                                          : (jj == 2) ? tr[2] - tr[1] : tr[1] - tr[3];
                             const unsigned h0a = pk_e(v[0], v[1]), h0b = pk_e(v[2], v[3]);
                             const unsigned h1a = pk_e(v[0] - pk_lo(h0a), v[1] - pk_hi(h0a));
                             const unsigned h1b = pk_e(v[2] - pk_lo(h0b), v[3] - pk_hi(h0b));
@@ -873,6 +992,7 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
 #endif
                             }
                         }
+                    }
                 }
             }
             XT(9)
