@@ -82,7 +82,7 @@ __device__ __forceinline__ int wino_slot(const A &a, int c) {
     if (!a.dev_counts) return c < a.n ? c : -1;
     int cum = 0;
     for (int it = 0; it < a.nitems; ++it) {
-        const int cnt = min(a.dev_counts[it], a.start[it + 1] - a.start[it]);
+        const int cnt = max(0, min(a.dev_counts[it], a.start[it + 1] - a.start[it]));     // (-1 = "take the host path": no proposals)
         if (c < cum + cnt) return a.start[it] + (c - cum);
         cum += cnt;
     }

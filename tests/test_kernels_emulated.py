@@ -320,21 +320,24 @@ def test_device_filter_coarse_long_lists(n, distinct, emu):
     assert torch.equal(got[0][0], r) and torch.equal(got[0][1], rs)
 
 
+@pytest.mark.parametrize("counts", [[2, 0, 1], [2, -1, 1]])
 @pytest.mark.parametrize("mode", ["fp16x2w", "fp16x2"])
-def test_regress_with_device_counts(mode, emu, sd):
+def test_regress_with_device_counts(mode, counts, emu, sd):
     """p2p_regress_batch_dev: every item owns `stride` slots, the first counts[i] hold proposals; used slots equal the
-    per-item call bit for bit, the others are not touched."""
+    per-item call bit for bit, the others are not touched.  A count of -1 (the device filter's "take the host path") is an
+    item without proposals and must not shift the items behind it."""
     import ctypes
     from patch2pix_amd import _lib as real
     sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
     mid = emu_lib.regressor_create(emu, sub("regress_mid."), mode)
     fine = emu_lib.regressor_create(emu, sub("regress_fine."), mode)
-    sizes, counts, stride = [(16, 24), (24, 16), (8, 8)], [2, 0, 1], 3
+    sizes, stride = [(16, 24), (24, 16), (8, 8)], 3
     g = torch.Generator().manual_seed(4)
     pyr1 = [synthetic.make_pyramid(200 + i, h, w)[:4] for i, (h, w) in enumerate(sizes)]
     pyr2 = [synthetic.make_pyramid(300 + i, h, w)[:4] for i, (h, w) in enumerate(sizes)]
     props = torch.zeros(len(sizes), stride, 4, dtype=torch.int64)
     for i, ((h, w), c) in enumerate(zip(sizes, counts)):
+        c = max(c, 0)
         props[i, :c] = torch.stack([torch.randint(0, w + 1, (c,), generator=g), torch.randint(0, h + 1, (c,), generator=g),
                                     torch.randint(0, w + 1, (c,), generator=g), torch.randint(0, h + 1, (c,), generator=g)], 1)
     arr_a, arr_b, keep = (real.Pyramid * len(sizes))(), (real.Pyramid * len(sizes))(), []
@@ -353,6 +356,7 @@ def test_regress_with_device_counts(mode, emu, sd):
                                                  props.data_ptr(), 0, m1.data_ptr(), p1.data_ptr(), None, m2.data_ptr(),
                                                  p2.data_ptr(), None, wsp, wsn, None), "p2p_regress_batch_dev")
     for i, c in enumerate(counts):
+        c = max(c, 0)
         used, rest = slice(i * stride, i * stride + c), slice(i * stride + c, (i + 1) * stride)
         if c:
             single = emu_lib.regress(emu, mid, fine, pyr1[i], pyr2[i], props[i, :c].contiguous())
