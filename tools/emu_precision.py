@@ -28,7 +28,7 @@ d1, d2 = [t.double() for t in p1[:4]], [t.double() for t in p2[:4]]
 ref_m, ref_p, ref_raw = orc.fine_level(d1, d2, props, mid64)
 o_m, o_p, o_raw = orc.fine_level(p1[:4], p2[:4], props, mid32)
 print(f"torch-CPU fp32 oracle: raw {(o_raw.double() - ref_raw).abs().max():.2e}  px {(o_m.double() - ref_m).abs().max():.2e}")
-for mode in ("f32", "fp16x2"):
+for mode in ("f32", "fp16x2", "fp16x2w"):
     mid = emu_lib.regressor_create(emu, sub("regress_mid."), mode)
     fine = emu_lib.regressor_create(emu, sub("regress_fine."), mode)
     out = emu_lib.regress(emu, mid, fine, p1[:4], p2[:4], props)

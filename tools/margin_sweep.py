@@ -12,7 +12,7 @@ p1 = synthetic.make_pyramid(7, H, W); p2 = synthetic.make_pyramid(8, H, W)
 g = torch.Generator().manual_seed(9)
 props = torch.stack([torch.randint(0, W + 1, (n,), generator=g), torch.randint(0, H + 1, (n,), generator=g),
                      torch.randint(0, W + 1, (n,), generator=g), torch.randint(0, H + 1, (n,), generator=g)], 1)
-print(f"{'setting':34s} " + " ".join(f"{m:>21s}" for m in ("f32", "fp16x2")) + "   (max |err| mid px / fine px vs fp64)")
+print(f"{'setting':34s} " + " ".join(f"{m:>21s}" for m in ("f32", "fp16x2", "fp16x2w")) + "   (max |err| mid px / fine px vs fp64)")
 worst = {}
 # the regular grid, then the range extremes that matter for the fp16 planes (features 1e-3 ... 3e3, weights 0.01 ... 50)
 GRID = [(w, v, f) for w in (0.25, 0.5, 1.0, 2.0, 4.0) for v in (1.0, 8.0) for f in (1.0, 30.0)]
@@ -36,7 +36,7 @@ for wscale, var_spread, fscale in GRID:
             ref_m, _, _ = orc.fine_level(d1, d2, props, mid64)
             g1 = [t.to(dev) for t in q1]; g2 = [t.to(dev) for t in q2]
             cells = []
-            for mode in ("f32", "fp16x2"):
+            for mode in ("f32", "fp16x2", "fp16x2w"):
                 mid.set_mode(mode); fine.set_mode(mode)
                 out = ops.regress(mid, fine, g1, g2, props.to(dev))
                 torch.cuda.synchronize()

@@ -17,7 +17,7 @@ for (H, W, n) in [(96, 128, 257), (480, 640, 400)]:
     props[0] = torch.tensor([0, 0, W, H]); props[1] = torch.tensor([W, H, 0, 0])
     g1 = [t.to(dev) for t in p1[:4]]; g2 = [t.to(dev) for t in p2[:4]]
     ref_m, ref_p, ref_raw = orc.fine_level([t.double() for t in p1[:4]], [t.double() for t in p2[:4]], props, mid_p64)
-    for mode in ("f32", "fp16x2"):
+    for mode in ("f32", "fp16x2", "fp16x2w"):
         mid.set_mode(mode); fine.set_mode(mode)
         out = ops.regress(mid, fine, g1, g2, props.to(dev), want_raw=True)
         torch.cuda.synchronize()
