@@ -51,6 +51,12 @@
 //     turns on the matrix pipe between bare s_barriers; in conv1 (ingest-bound) they run free in a staggered order
 //     (waves 0-3: pixel range, cell range, fold; waves 4-7: cell range, fold, pixel range), so that every wave's loads
 //     are in flight all the time and a fold sits beside the partner's MFMAs.
+//
+// Two instantiations.  regress_h2_kernel<false> is the kernel described above (mode P2P_REGRESS_FP16X2: both levels, both
+// convolutions and the FC tail in ONE persistent launch).  regress_h2_kernel<true> is the first launch of the default mode
+// P2P_REGRESS_FP16X2W (regress_wino.hip): one level, a chunk of the proposals, gather + conv1 exactly as above, and then --
+// instead of conv2 -- the Winograd input transform B^T d B of H = BN1(conv1), written to global memory in the block layout
+// the GEMM kernel copies into LDS; the gather of the work-group's next proposal is in flight during that write-out.
 #define XNPL 2                          // planes per operand; XUB = bytes of a weight unit per wave (XNPL x 1 KiB)
 #include "regress_common.h"
 

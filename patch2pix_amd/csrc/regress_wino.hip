@@ -18,7 +18,8 @@
 //
 // wino_gemm_kernel.  Work-group = 128 rows (8 proposals x 16 tiles) x 128 output channels, 8 waves (two per SIMD: issuing an
 // LDS-DMA piece stalls a wave for ~60-100 cycles, longer than an MFMA lasts, so a single wave per SIMD left the matrix pipe
-// 45 % busy; its sibling now issues meanwhile), each a 64 x 32 tile = 2 x 1 MFMA tiles: M (32) + Y (128) accumulators.  K = 16 positions x 512 channels is walked in 256 stages of 32 channels; a stage's operands are two 16 KB blocks
+// 45 % busy; its sibling now issues meanwhile), each a 64 x 32 tile = 2 x 1 MFMA tiles: M (32) + Y (128) accumulators.
+// K = 16 positions x 512 channels is walked in 256 stages of 32 channels; a stage's operands are two 16 KB blocks
 // (A: U rows, B: filters) whose GLOBAL layout is the LDS image -- [plane 2][row 128][4 pieces of 16 B], piece q of a row
 // stored at slot q ^ ((row >> 2) & 3), which puts the 16 lanes of every ds_read_b128 service group on 16 different bank
 // slots -- so they are copied by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write) into a ring of four
