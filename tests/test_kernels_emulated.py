@@ -320,8 +320,7 @@ def test_device_filter_coarse_long_lists(n, distinct, emu):
     assert torch.equal(got[0][0], r) and torch.equal(got[0][1], rs)
 
 
-@pytest.mark.parametrize("counts", [[2, 0, 1], [2, -1, 1]])
-@pytest.mark.parametrize("mode", ["fp16x2w", "fp16x2"])
+@pytest.mark.parametrize("mode,counts", [("fp16x2w", [2, -1, 1]), ("fp16x2", [2, 0, 1])])
 def test_regress_with_device_counts(mode, counts, emu, sd):
     """p2p_regress_batch_dev: every item owns `stride` slots, the first counts[i] hold proposals; used slots equal the
     per-item call bit for bit, the others are not touched.  A count of -1 (the device filter's "take the host path") is an
