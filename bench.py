@@ -99,19 +99,51 @@ def parse():
 
 def self_launch(ngpus):
     """`python bench.py --gpus N` as a PLAIN command (no WORLD_SIZE in the environment): become
-    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <argv>`,
+    `python -m torch.distributed.run --standalone --local-addr 127.0.0.1 --nnodes=1 --nproc-per-node N bench.py <argv>`,
     one rank per GPU; the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* like under an external launcher."""
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher binds its own rendezvous endpoint on a free port of --local-addr (no port is picked here and
+    # closed again before the launcher binds it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={ngpus}", os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL between processes needs it on these hosts
     env.setdefault("OMP_NUM_THREADS", "4")
     sys.stdout.flush()
     os.execvpe(cmd[0], cmd, env)
+
+
+def init_dist(world, dev, force=False):
+    """The run's process group: `nccl` (= RCCL on ROCm) with the rank's GPU as `device_id`.  Also at N = 1 (unless
+    P2P_BENCH_DIST=0): a world-size-1 group, so that the driver's single-GPU line goes through process-group creation, the
+    barriers and the three all_gathers of gather_matches ON THE GPU -- the multi-GPU code path minus the xGMI links.  Under a
+    launcher the rendezvous comes from the environment (MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE); a plain
+    single-process run uses an in-process store (nothing to resolve, no port to race for).
+    -> (torch.distributed or None, info dict for the JSON line)."""
+    if world == 1 and not force and os.environ.get("P2P_BENCH_DIST", "1") == "0":
+        return None, {"backend": None, "note": "P2P_BENCH_DIST=0: no process group at N = 1"}
+    import torch.distributed as dist
+    try:
+        if "MASTER_ADDR" in os.environ and "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("nccl", store=dist.HashStore(), rank=0, world_size=1, device_id=dev)
+        t = torch.ones(1, device=dev)
+        dist.all_reduce(t)                       # the communicator is created lazily: fail here, not inside the timed region
+        torch.cuda.synchronize()
+        assert float(t) == float(world)
+    except Exception as e:
+        if world > 1:
+            raise
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return None, {"backend": None, "error": repr(e)}
+    try:
+        rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:                       # informational only
+        rccl = repr(e)
+    return dist, {"backend": dist.get_backend(), "world": world, "rccl_version": rccl, "hip_runtime": torch.version.hip,
+                  "torch": torch.__version__,
+                  "collectives_in_timed_region": "2 barriers + all_gather of counts (int64), rows (f32 [M,9]) and pair ids (int64)"}
 
 
 def rendezvous_check(world, rank, local_rank):
@@ -578,10 +610,7 @@ def main():
     if os.environ.get("P2P_NUMA_PIN", "1") != "0":
         from patch2pix_amd.utils.host import pin_process_to_gpu
         pinned_cpus = pin_process_to_gpu(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+    dist, dist_info = init_dist(world, dev)
 
     from patch2pix_amd import ops
     from patch2pix_amd.utils import synthetic
@@ -652,6 +681,7 @@ def main():
                              "note": "compulsory bytes of the whole path per pair (SURVEY 8d) x pairs/s per GPU; the path "
                                      "is MFMA-bound (4300 flop/B), so this fraction is << 1 by construction"},
             "per_gpu_pairs_per_s": value / world,
+            "dist": dist_info,
             "per_rank_pairs_per_s": [r[1] for r in per_rank],
             "per_rank_regress_launch_ms": [r[2] for r in per_rank],
             "per_rank_roofline_frac": [r[3] for r in per_rank],

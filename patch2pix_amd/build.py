@@ -61,6 +61,12 @@ def build(force=False, verbose=True):
     import hashlib
     from concurrent.futures import ThreadPoolExecutor
     headers = [d for d in _deps() if d.endswith(".h")]
+    # the compiler is part of an object's identity: after a ROCm / HIPCC switch stale objects must not be relinked
+    try:
+        compiler_id = hipcc + "\n" + subprocess.run([hipcc, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                                    text=True).stdout
+    except OSError as e:
+        compiler_id = hipcc + "\n" + repr(e)
 
     def compile_one(src):
         """One translation unit; skipped when the object on disk was built from the same source + headers + flags."""
@@ -68,6 +74,7 @@ def build(force=False, verbose=True):
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
                "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
         h = hashlib.sha256(" ".join(cmd[1:-3]).encode())
+        h.update(compiler_id.encode())
         for d in [os.path.join(CSRC, src)] + headers:
             h.update(os.path.basename(d).encode())
             h.update(open(d, "rb").read())

@@ -564,9 +564,11 @@ static int regress_batch_impl(const p2p_regressor *reg1, const p2p_regressor *re
         // the direct mode only parks the pooled features and the next level's proposals; the Winograd mode also the
         // transformed conv2 input of a chunk (p2p_regress_workspace_bytes_mode)
         const size_t need = (reg1->mode == P2P_REGRESS_FP16X2W ? regress_ws_floats((size_t)most) : regress_ws_base_floats((size_t)most)) * sizeof(float);
-        P2P_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace & 127) == 0,
-                    P2P_EINVAL, "p2p_regress: workspace of %zu bytes (p2p_regress_workspace_bytes, 128-byte aligned) needed, got %zu",
-                    need, workspace ? workspace_bytes : (size_t)0);
+        P2P_REQUIRE(workspace && ((uintptr_t)workspace & 127) == 0, P2P_EINVAL,
+                    "p2p_regress: a 128-byte aligned workspace of %zu bytes (p2p_regress_workspace_bytes_mode) is needed", need);
+        // too small: P2P_ENOMEM like every other workspace check of the library (a caller may grow the buffer and retry)
+        P2P_REQUIRE(workspace_bytes >= need, P2P_ENOMEM,
+                    "p2p_regress: workspace of %zu bytes (p2p_regress_workspace_bytes_mode) needed, got %zu", need, workspace_bytes);
     }
     int dev = 0;
     P2P_HIP_CHECK(hipGetDevice(&dev));

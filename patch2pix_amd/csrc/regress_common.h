@@ -17,6 +17,7 @@ struct RegDev {
     const float *fc1t, *fc1b, *bnf1s, *bnf1b, *fc2t, *fc2b, *bnf2s, *bnf2b, *fc3, *fc3b;
     const float *fc1p, *fc2p;           // fc1 / fc2 in v_mfma_f32_16x16x4_f32 fragment order (fc_batch_parse)
     const float *ww2, *bn2s_w;          // conv2 as Winograd-transformed filter blocks + its BN scale (regress_wino.hip)
+    const float *wh1w, *wl3;            // FP16X2W: conv1's weight stream without level 3; level 3 as GEMM blocks (regress_l3.hip)
 };
 
 struct ItemDev {
@@ -40,26 +41,63 @@ struct RegressArgs {
     unsigned char *wU;
     float *hinv;
     int lvl0, p0, p1, mblocks;
+    // the level-3 part of conv1 comes from regress_l3.hip: metadata and T3 of the round that starts at compact proposal l3c0
+    const float *l3meta, *l3T;
+    int l3c0;
 };
 
 // scratch of the kernels whose FC tail is batched over a work-group's proposals (regress_h2.hip): the pooled
 // convolution features V [level][n][512] and the un-truncated mid matches [n][4] the fine level starts from
 constexpr int FC_ROWS = 16;             // proposals per FC batch = rows of a v_mfma_f32_16x16x4_f32 tile
-// P2P_REGRESS_FP16X2W appends: the inverse H scale per proposal of a chunk, and the transformed conv2 input of a chunk of at
-// most WINO_CHUNK proposals (16 positions x 16 tiles x 512 channels x 2 fp16 planes = 512 KiB per proposal), as the A
-// blocks of wino_gemm_kernel: [position 16][row block of 8 proposals][K chunk 16][WINO_BLK bytes]
+// P2P_REGRESS_FP16X2W appends: the inverse H scale per proposal of a chunk, and the transformed conv2 input of a chunk of
+// proposals (16 positions x 16 tiles x 512 channels x 2 fp16 planes = 512 KiB per proposal), as the A
+// blocks of wino_gemm_kernel: [position 16][row block of 8 proposals][K chunk 16][WINO_BLK bytes]; then the level-3 part of
+// conv1 (regress_l3.hip): per-proposal metadata, the gathered level-3 cells as GEMM rows, and the GEMM's output T3
 constexpr int WINO_BLK = 16384;         // [plane 2][row 128][32 K] fp16
 #ifndef P2P_WINO_CHUNK
-#define P2P_WINO_CHUNK 2048
+#define P2P_WINO_CHUNK 2560
 #endif
-constexpr int WINO_CHUNK = P2P_WINO_CHUNK;   // proposals per conv1 -> GEMM round (a whole number of rounds of both kernels on 256 CUs)
+// Proposals per conv1 -> GEMM round.  A call's n proposals are cut into ceil(units / (WINO_CHUNK / 256)) chunks of whole
+// units of 256 proposals (= whole rounds of the persistent conv1 launch on 256 compute units, two rounds of the GEMM's
+// 128-row x 128-column work-groups), sizes as even as the units allow: 6400 -> 2304 + 2048 + 2048 (a fixed chunk of 2048
+// left a last launch of 256 proposals = half-empty GEMM round and a full set of fixed per-launch costs).
+constexpr int WINO_CHUNK = P2P_WINO_CHUNK;
+static_assert(WINO_CHUNK % 256 == 0 && WINO_CHUNK >= 256, "chunks are whole units of 256 proposals");
+static inline int wino_nchunks(size_t n) {
+    const size_t units = (n + 255) / 256, per = WINO_CHUNK / 256;
+    return (int)std::max<size_t>(1, (units + per - 1) / per);
+}
+// proposals [*p0, *p1) of chunk c (0 <= c < wino_nchunks(n))
+static inline void wino_chunk_range(size_t n, int c, int *p0, int *p1) {
+    const size_t units = (n + 255) / 256, nch = (size_t)wino_nchunks(n), base = units / nch, rem = units % nch;
+    const size_t u0 = (size_t)c * base + std::min<size_t>((size_t)c, rem), u1 = u0 + base + ((size_t)c < rem ? 1 : 0);
+    *p0 = (int)std::min(n, u0 * 256);
+    *p1 = (int)std::min(n, u1 * 256);
+}
 static inline size_t regress_ws_base_floats(size_t n) { return ((2 * n * 512 + 31) & ~size_t(31)) + 4 * n + 32; }
 static inline size_t wino_hinv_offset_floats(size_t n) { return (regress_ws_base_floats(n) + 63) & ~size_t(63); }
-static inline size_t wino_chunk_rows(size_t n) { return (std::min(n, (size_t)WINO_CHUNK) + 7) & ~size_t(7); }
-static inline size_t wino_u_offset_floats(size_t n) { return (wino_hinv_offset_floats(n) + wino_chunk_rows(n) + 63) & ~size_t(63); }
-static inline size_t regress_ws_floats(size_t n) {
-    return wino_u_offset_floats(n) + (size_t)16 * (wino_chunk_rows(n) / 8) * 16 * (WINO_BLK / 4);
+static inline size_t wino_chunk_rows(size_t n) {        // rows of the largest chunk (the first), rounded to a row block of 8 proposals
+    int p0, p1;
+    wino_chunk_range(n, 0, &p0, &p1);
+    return ((size_t)(p1 - p0) + 7) & ~size_t(7);
 }
+static inline size_t wino_u_offset_floats(size_t n) { return (wino_hinv_offset_floats(n) + wino_chunk_rows(n) + 63) & ~size_t(63); }
+// level 3 of conv1 as batched GEMMs (regress_l3.hip), at most L3_CHUNK proposals per round:
+//   meta [c][img 2][12]: sum of squares of the 9 gathered level-3 cells (the per-pixel L2 scale needs them), [9] = the biased
+//        exponent of the largest gathered magnitude (int bits): the rows are scaled by 2^(138 - that) into [2^11, 2^12)
+//   A3   [img 2][row block][K chunk 4][WINO_BLK]: rows 9 c + cell, 128 channels, two fp16 planes, in the LDS image of the GEMM
+//   T3   [c][step = tap * 2 + img][wave 8][cell 9][64 n] fp32: what wave `wave` of regress_h2_kernel<true> folds in step `step`
+constexpr int L3_CHUNK = 8192;          // T3 of a round <= 2.7 GB (byte offsets stay below 2^32)
+constexpr int L3_META = 12;
+constexpr size_t L3_T3_FLOATS = (size_t)18 * 8 * 9 * 64;      // per proposal: 331 776 bytes
+static inline size_t l3_rows(size_t n) { return std::min(n, (size_t)L3_CHUNK); }
+static inline size_t l3_rowblocks(size_t n) { return (9 * l3_rows(n) + 127) / 128; }
+static inline size_t l3_meta_offset_floats(size_t n) {
+    return (wino_u_offset_floats(n) + (size_t)16 * (wino_chunk_rows(n) / 8) * 16 * (WINO_BLK / 4) + 63) & ~size_t(63);
+}
+static inline size_t l3_a_offset_floats(size_t n) { return (l3_meta_offset_floats(n) + l3_rows(n) * 2 * L3_META + 63) & ~size_t(63); }
+static inline size_t l3_t_offset_floats(size_t n) { return l3_a_offset_floats(n) + 2 * l3_rowblocks(n) * 4 * (WINO_BLK / 4); }
+static inline size_t regress_ws_floats(size_t n) { return l3_t_offset_floats(n) + l3_rows(n) * L3_T3_FLOATS; }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -337,6 +375,18 @@ constexpr size_t WH2_FLOATS = (size_t)8 * (S2_UNITS + XPF) * 512;
 void pack_h2_weights(const float *conv1_w, const float *conv2_w, float *wh1, float *wh2, int *t1, int *t2);      // host
 int launch_regress_h2(const RegressArgs &a, int n, hipStream_t stream);
 int launch_regress_h2_conv1(const RegressArgs &a, int n, hipStream_t stream);   // conv1 -> transformed conv2 input (FP16X2W)
+// FP16X2W: conv1's stream without the level-3 units: per wave 8 units of level 0, then per (tap, image) step 8 units of level 1
+// (pixel range) and 8 of level 2 (cell range) -- waves 4-7 the cell range first
+constexpr int S1W_SLABS = 4 + 9 * 2 * 8;
+constexpr int S1W_UNITS = 2 * S1W_SLABS;
+constexpr size_t WH1W_FLOATS = (size_t)8 * (S1W_UNITS + XPF) * 512;
+void pack_h2w_conv1(const float *conv1_w, const int *t1, float *wh1w);            // host (t1: the exponents of pack_h2_weights)
+
+// regress_l3.hip: level 3 of conv1 (128 of the 259 channels per image, 3 x 3 distinct cells per image and proposal) as 18
+// GEMMs (tap, image) over the cells of ALL proposals; filter blocks [img 2][tap 9][column block 4][K chunk 4][WINO_BLK]
+constexpr size_t WL3_FLOATS = (size_t)2 * 9 * 4 * 4 * (WINO_BLK / 4);
+void pack_l3_weights(const float *conv1_w, const int *t1, float *wl3);            // host
+int launch_regress_l3(const RegressArgs &a, int c0, int c1, float *meta, unsigned char *A3, float *T3, hipStream_t stream);
 
 // regress_wino.hip: conv2 as Winograd F(2x2, 3x3) GEMMs; filter blocks [position 16][column block 4][K chunk 16][WINO_BLK]
 constexpr size_t WW2_FLOATS = (size_t)16 * 4 * 16 * (WINO_BLK / 4);

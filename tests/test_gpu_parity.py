@@ -271,7 +271,8 @@ def test_fine_empty_and_single(dev, ops, weights):
 
 def test_regress_workspace_is_sized_per_mode(dev, ops, weights):
     """p2p_regress_workspace_bytes_mode: the direct fp16x2 mode parks 4 KB per proposal, the Winograd mode also the
-    transformed conv2 input of a chunk; a buffer that is too small for the handle's mode is P2P_EINVAL, never a fault."""
+    transformed conv2 input of a chunk; a buffer that is too small for the handle's mode is P2P_ENOMEM (-4, like the
+    library's other workspace checks), never a fault."""
     import ctypes
     from patch2pix_amd import _lib
     _, _, mid_w, fine_w = weights
@@ -299,7 +300,7 @@ def test_regress_workspace_is_sized_per_mode(dev, ops, weights):
     assert call(need) == 0
     torch.cuda.synchronize()
     want = m2.clone()
-    assert call(need - 256) == -1 and b"workspace" in _lib.p2p_last_error()
+    assert call(need - 256) == -4 and b"workspace" in _lib.p2p_last_error()
     assert call(_lib.p2p_regress_workspace_bytes(n)) == 0
     torch.cuda.synchronize()
     assert torch.equal(m2, want)

@@ -161,7 +161,7 @@ def test_regressor_chain_and_image_borders(mode, emu, sd):
     assert (out["probs2"] - ref_finep).abs().max() <= SCORE_TOL
 
 
-@pytest.mark.parametrize("mode", ["fp16x2"])
+@pytest.mark.parametrize("mode", ["fp16x2w", "fp16x2"])
 def test_regress_batch_items_of_different_sizes(mode, emu, sd):
     """p2p_regress_batch over items (pairs) of different image sizes, one of them empty == one call per item."""
     import ctypes
