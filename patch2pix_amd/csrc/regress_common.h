@@ -76,10 +76,8 @@ static inline void wino_chunk_range(size_t n, int c, int *p0, int *p1) {
 }
 static inline size_t regress_ws_base_floats(size_t n) { return ((2 * n * 512 + 31) & ~size_t(31)) + 4 * n + 32; }
 static inline size_t wino_hinv_offset_floats(size_t n) { return (regress_ws_base_floats(n) + 63) & ~size_t(63); }
-static inline size_t wino_chunk_rows(size_t n) {        // rows of the largest chunk (the first), rounded to a row block of 8 proposals
-    int p0, p1;
-    wino_chunk_range(n, 0, &p0, &p1);
-    return ((size_t)(p1 - p0) + 7) & ~size_t(7);
+static inline size_t wino_chunk_rows(size_t n) {        // rows of the transformed-input buffer: no chunk of any round is larger
+    return (std::min(n, (size_t)WINO_CHUNK) + 7) & ~size_t(7);
 }
 static inline size_t wino_u_offset_floats(size_t n) { return (wino_hinv_offset_floats(n) + wino_chunk_rows(n) + 63) & ~size_t(63); }
 // level 3 of conv1 as batched GEMMs (regress_l3.hip), at most L3_CHUNK proposals per round:
@@ -373,6 +371,7 @@ constexpr int XPF = 8;                   // units the weight prefetch may run pa
 constexpr size_t WH1_FLOATS = (size_t)8 * (S1_UNITS + XPF) * 512;
 constexpr size_t WH2_FLOATS = (size_t)8 * (S2_UNITS + XPF) * 512;
 void pack_h2_weights(const float *conv1_w, const float *conv2_w, float *wh1, float *wh2, int *t1, int *t2);      // host
+void conv1_channel_exponents(const float *conv1_w, int *t1);                      // host: the t1 of pack_h2_weights
 int launch_regress_h2(const RegressArgs &a, int n, hipStream_t stream);
 int launch_regress_h2_conv1(const RegressArgs &a, int n, hipStream_t stream);   // conv1 -> transformed conv2 input (FP16X2W)
 // FP16X2W: conv1's stream without the level-3 units: per wave 8 units of level 0, then per (tap, image) step 8 units of level 1

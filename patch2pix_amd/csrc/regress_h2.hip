@@ -137,11 +137,14 @@ constexpr int HST = 128 * 2 + 16, HPL = 66 * HST;                 // 272, 17952
 constexpr int HCHUNK = XNPL * HPL;                                // 35904: planes of chunk c start at c * HCHUNK
 constexpr int XCONV2B = 4 * HCHUNK;
 // both phases, then the FC batch of the level (fc_batch_parse) over the whole allocation
-constexpr int XSM_MISC = (XCONV1B > XCONV2B) ? XCONV1B : XCONV2B;  // [16] floats: 8-11 the proposal, 12-14 the fp16 scale reductions
+constexpr int XSM_MISC = (XCONV1B > XCONV2B) ? XCONV1B : XCONV2B;  // [64] floats: 4-7 the next proposal (WINO), 8-11 the proposal,
+                                                                  // 12-14 the fp16 scale reductions, 16-39 the level-3 metadata
+                                                                  // of the proposal (WINO; regress_l3.hip: [img 2][L3_META])
+constexpr int XMISC_FLOATS = 64;
 #ifdef P2P_X3_TIMING
-constexpr int XSM_BYTES = XSM_MISC + 16 * 4 + 8 * 16 * 4;
+constexpr int XSM_BYTES = XSM_MISC + XMISC_FLOATS * 4 + 8 * 16 * 4;
 #else
-constexpr int XSM_BYTES = XSM_MISC + 16 * 4;
+constexpr int XSM_BYTES = XSM_MISC + XMISC_FLOATS * 4;
 #endif
 static_assert(FC_LDS_BYTES <= XSM_MISC, "the FC batch stages its rows over the convolution buffers");
 static_assert(2 * XTMPIMG <= XSHR && 64 * XA0ST <= XSHR, "the shared region is sized by the fold buffers");
@@ -189,7 +192,7 @@ __device__ __forceinline__ void splitn(const f32x4 &xa, const f32x4 &xb, float s
 #endif
 #ifdef P2P_X3_TIMING                    // phase lengths in s_memtime ticks -> args.raw[0] (tools/x3_timing.py)
 // per-wave counters in LDS (14 more live SGPRs spill): [wave][16] unsigned behind the misc block
-#define XTL_() ((unsigned *)(smb + XSM_MISC + 64) + wave * 16)
+#define XTL_() ((unsigned *)(smb + XSM_MISC + XMISC_FLOATS * 4) + wave * 16)
 #define XT_DECL
 #define XT_START { const unsigned n_ = (unsigned)__builtin_amdgcn_s_memtime(); if (P2P_LANE_ID() < 16) XTL_()[P2P_LANE_ID()] = (P2P_LANE_ID() == 15) ? n_ : 0u; }
 #define XT(i) { const unsigned n_ = (unsigned)__builtin_amdgcn_s_memtime(); if (P2P_LANE_ID() == 0) { unsigned *x_ = XTL_(); x_[i] += n_ - x_[15]; x_[15] = n_; } }
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
         const RegDev &R_ = args.reg[lvl];
         // WINO: the gather of proposal i + 1 is issued before the transform + write-out of proposal i (its ~40 scattered loads
         // per thread land in these registers while that phase runs) and committed to LDS at the top of its own iteration
-        float gn0[2][2], gn1[2][11], gn2[2][4], gn3[2][3];
+        float gn0[2][2], gn1[2][11], gn2[2][4];
         bool pre = false;                    // gn* hold the gather of the proposal the next iteration starts with
         auto gather_loads = [&](int xa_, int ya_, int xb_, int yb_, const ItemDev &J) {
             int tv = wave * 64 + P2P_LANE_ID();
@@ -406,10 +409,10 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                     }
                 }
 #pragma unroll
-                for (int j = 1; j < 4; ++j) {
-                    const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
-                    const int Cc = (j == 3) ? 128 : 64;
-                    const int nk = (j == 1) ? 11 : (j == 2) ? 4 : 3;
+                for (int j = 1; j < 3; ++j) {        // (level 3: regress_l3.hip)
+                    const int Rr = (j == 1) ? 9 : 5;
+                    const int Cc = 64;
+                    const int nk = (j == 1) ? 11 : 4;
                     const int Hj = Hh >> j, Wj = Ww >> j;
                     const int Ha = level_dim(Hh, j), Wa = level_dim(Ww, j);
                     const int r0 = clampi(y0 >> j, 0, Hj - 1);
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                         const int cc = rem - r * Rr;
                         const float v = (e < Cc * Rr * Rr)
                                             ? src[((size_t)c * Ha + min(r0 + r, Hj - 1)) * Wa + min(c0 + cc, Wj - 1)] : 0.f;
-                        if (j == 1) gn1[img][k] = v; else if (j == 2) gn2[img][k] = v; else gn3[img][k] = v;
+                        if (j == 1) gn1[img][k] = v; else gn2[img][k] = v;
                     }
                 }
             }
@@ -441,19 +444,19 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                 }
                 unsigned char *tb = smb + img * XIMG;
 #pragma unroll
-                for (int j = 1; j < 4; ++j) {
-                    const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
-                    const int Cc = (j == 3) ? 128 : 64;
-                    const int nk = (j == 1) ? 11 : (j == 2) ? 4 : 3;
+                for (int j = 1; j < 3; ++j) {
+                    const int Rr = (j == 1) ? 9 : 5;
+                    const int Cc = 64;
+                    const int nk = (j == 1) ? 11 : 4;
 #pragma unroll
                     for (int k = 0; k < nk; ++k) {
                         const int e = tv + k * NT;
                         if (e < Cc * Rr * Rr) {
                             const int c = e / (Rr * Rr);
                             const int rem = e - c * (Rr * Rr);
-                            const float v = (j == 1) ? gn1[img][k] : (j == 2) ? gn2[img][k] : gn3[img][k];
+                            const float v = (j == 1) ? gn1[img][k] : gn2[img][k];
                             if (j == 1) *(float *)(tb + XOFF1 + (rem / 9) * XRP1 + (rem % 9) * XST1 + c * 4) = v;
-                            else *(float *)(smb + XSHARED + img * XTMPIMG + ((j == 2) ? rem * XTMP2ST : XTMP3 + rem * XTMP3ST) + c * 4) = v;
+                            else *(float *)(smb + XSHARED + img * XTMPIMG + rem * XTMP2ST + c * 4) = v;
                         }
                     }
                 }
@@ -493,6 +496,9 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                 else v = (float)((const long long *)args.proposals)[(size_t)nprop * 4 + q];
                 misc[4 + q] = v;
             }
+        }
+        if constexpr (WINO) {                // level 3 of this proposal (regress_l3.hip): cell sums of squares + exponent, per image
+            if (tq >= 8 && tq < 8 + 2 * L3_META) misc[16 + tq - 8] = args.l3meta[(size_t)(cprop - args.l3c0) * (2 * L3_META) + (tq - 8)];
         }
         // per-level reductions behind the power-of-two operand scales: misc[12 + img] = smallest per-pixel L2 scale of the
         // image (float bits, atomic min), misc[14] = largest |H| (float bits, atomic max)
@@ -615,8 +621,9 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                 for (int c = 0; c < 3; ++c) ss = fmaf(p[c * 256], p[c * 256], ss);
             }
             const int c2 = patch_cell(XY0(img), py, 2, I.H[img]) * 5 + patch_cell(XX0(img), px, 2, I.W[img]);
+            const int c3 = patch_cell(XY0(img), py, 3, I.H[img]) * 3 + patch_cell(XX0(img), px, 3, I.W[img]);
 #pragma unroll
-            for (int j = 1; j < 4; ++j) {
+            for (int j = 1; j < (WINO ? 3 : 4); ++j) {
                 const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
                 const int Cc = (j == 3) ? 128 : 64;
                 const int cjy = patch_cell(XY0(img), py, j, I.H[img]), cjx = patch_cell(XX0(img), px, j, I.W[img]);
@@ -628,13 +635,14 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                     ss = fmaf(v[0], v[0], ss); ss = fmaf(v[1], v[1], ss); ss = fmaf(v[2], v[2], ss); ss = fmaf(v[3], v[3], ss);
                 }
             }
+            if constexpr (WINO) ss += misc[16 + img * L3_META + c3];      // level 3: summed by l3_prep_kernel
             const float sc = 1.0f / sqrtf(ss + 1e-6f);
             // fp16 operands carry power-of-two scales (header): per-pixel-normalised values x 2^12; the fold table entry
             // needs the image's smallest scale and is written after the barrier
             scale[tidv] = sc * 4096.0f;
             atomicMin((int *)misc + 12 + img, __float_as_int(sc));
             sc_keep = sc;
-            c23_keep = c2 * XTROW | (patch_cell(XY0(img), py, 3, I.H[img]) * 3 + patch_cell(XX0(img), px, 3, I.W[img])) * XTROW << 16;
+            c23_keep = c2 * XTROW | c3 * XTROW << 16;
             if (tidv < 2 * 33) {     // ring = the zero padding of conv1: scale 0
                 const int im = tidv / 33, q = tidv - im * 33;
                 const int idx = (q < 17) ? q : (q - 16) * 17;
@@ -651,11 +659,12 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
             *(f32x2 *)(smb + XTAB + img * XTABIMG + ((py + 1) * 17 + px + 1) * 8) =
                 (f32x2){sc_keep * __int_as_float((254 - eb) << 23), __int_as_float(c23_keep)};
             // planes of levels 2 and 3 from their fp32 copy: 2 x (25 x 64 + 9 x 128) values
+            constexpr int XPLN = WINO ? 1600 : 2752;      // values per image: 25 x 64 (+ 9 x 128 of level 3)
 #pragma unroll
-            for (int k = 0; k < 11; ++k) {
+            for (int k = 0; k < (2 * XPLN + NT - 1) / NT; ++k) {
                 const int e = tidv + k * NT;
-                if (e < 2 * 2752) {
-                    const int im = (e >= 2752), r = e - im * 2752;
+                if (e < 2 * XPLN) {
+                    const int im = (e >= XPLN), r = e - im * XPLN;
                     const int ebi = clampi((((const int *)misc)[12 + im] >> 23) & 0xff, 13, 240);
                     const float mul = __int_as_float((ebi + 12) << 23);
                     const bool l2 = r < 1600;
@@ -693,7 +702,8 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
         const f32x16 zero16 = {0};
         {
             f32x4 R0[2], R1[2];
-            const unsigned char *wb = (const unsigned char *)R_.wh1 + (size_t)wave * (S1_UNITS + XPF) * XUB;
+            const unsigned char *wb = WINO ? (const unsigned char *)R_.wh1w + (size_t)wave * (S1W_UNITS + XPF) * XUB
+                                           : (const unsigned char *)R_.wh1 + (size_t)wave * (S1_UNITS + XPF) * XUB;
             const unsigned wlane = (tidv & 63) * 16;
             XLOADB(B0, 0) XLOADB(B1, 1) XLOADB(B2, 2) XLOADB(B3, 3) XLOADB(B4, 4) XLOADB(B5, 5)
             {   // level 0 of both images: 4 slabs of the pre-scaled block
@@ -714,6 +724,30 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
             float *Tw = (float *)(smb + XSHARED + (wave & (XT2N - 1)) * XTW) + l31;
             float *T3w = (float *)(smb + XSHARED + XT2N * XTW + wave * (9 * XTROW));
             const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
+            // WINO: the level-3 partial sums T3[step][this wave's 64 channels][9 cells] of the proposal were computed by
+            // l3_gemm_kernel (regress_l3.hip); 2304 contiguous bytes per (step, wave), copied by LDS-DMA straight into this wave's
+            // fold buffer one step ahead: step 0 here, step s + 1 right behind the fold of step s (the wave is the buffer's only
+            // reader).  Between that issue and the fold that reads the rows this wave issues >= 16 weight loads and consumes
+            // them; loads return in order, so XT3_WAIT's counted wait (never reached in practice) is what makes it formal.
+#ifdef XF_T3_SAME                       // timing experiment (wrong results): every proposal reads the (cache-resident) rows of the first
+#define XT3_PROP() 0
+#else
+#define XT3_PROP() (cprop - args.l3c0)
+#endif
+#ifdef XF_T3_NODMA                      // timing experiment (wrong results): the level-3 rows are never fetched
+#define XT3_ISSUE(step_)
+#else
+#define XT3_ISSUE(step_)                                                                                              \
+            if constexpr (WINO) {                                                                                     \
+                P2P_WAVE_SYNC();         /* every lane's reads of the previous rows are done */                         \
+                const unsigned char *g3_ = (const unsigned char *)args.l3T +                                          \
+                    ((size_t)XT3_PROP() * (18 * 8) + (unsigned)((step_) * 8 + wave)) * (9 * XTROW) + (unsigned)P2P_LANE_ID() * 16u; \
+                P2P_GLOBAL_LOAD_LDS16(g3_, (unsigned char *)T3w, 0); P2P_GLOBAL_LOAD_LDS16(g3_, (unsigned char *)T3w, 1024);   \
+                if (P2P_LANE_ID() < 16) P2P_GLOBAL_LOAD_LDS16(g3_, (unsigned char *)T3w, 2048);                        \
+            }
+#endif
+#define XT3_WAIT() if constexpr (WINO) { P2P_WAIT_VMCNT(16); }
+            XT3_ISSUE(0)
             // The K-ranges (tap, image) are walked in 18 steps.  A step = the pixel slabs of level 1 (P), the cell slabs
             // of levels 2 + 3 (C) and the fold (F).  Waves 0-3 run P(i) C(i) F(i); waves 4-7 -- each shares its SIMD with
             // one of waves 0-3 -- run C(i) F(i) P(i) (their weight stream is packed in that order), so that a fold, which
@@ -777,9 +811,17 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                     f32x16 t0, t1;
                     XPB_C0(grp)
 #if defined(XF_SKIP_C)
-                    t0 = acc00; t1 = acc01; XWADV(24) (void)q2; (void)q3;
+                    t0 = acc00; t1 = acc01; XWADV(WINO ? 8 : 24) (void)q2; (void)q3;
 #else
-                    {
+                    if constexpr (WINO) {
+                        (void)q3; (void)zero4;
+                        // level 2 only: 4 slabs of 16 channels, rows = level-2 cells (level 3: T3 rows from regress_l3.hip)
+                        XLOADP(S0, q2, YPL2)
+                        XGROUP4(XCSLAB(XHALFZ, S0, S1, q2 + 32, YPL2, B0, B1, B6, B7, 6),
+                                XCSLAB(XHALF, S1, S0, q2 + 64, YPL2, B2, B3, B0, B1, 8),
+                                XCSLAB(XHALF, S0, S1, q2 + 96, YPL2, B4, B5, B2, B3, 10),
+                                XCSLAB(XHALF, S1, S0, q2 + 96, YPL2, B6, B7, B4, B5, 12))
+                    } else {
                         (void)q3;
                         // level 3 first: 4 K steps of 32 channels x 4 n-tiles of 16 columns, rows = the 9 cells
                         const int l16 = (tidv & 15), kb = (tidv >> 4) & 3;
@@ -825,7 +867,18 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                         }
                     }
                     P2P_WAVE_SYNC();
+                    XT3_WAIT()
                     {
+                        // WINO: T3 carries the exponent of l3_prep_kernel (cells x 2^(138 - eb3)), the table entry that of the image's
+                        // level-2 planes (scale[pixel] x 2^(127 - eb)): T3 x 2^(eb3 + eb - 253) brings it to the table's scale
+                        float r3 = 1.0f;
+                        if constexpr (WINO) {
+                            int mo3 = 12;
+                            P2P_OPAQUE(mo3);
+                            const int eb = clampi((((const int *)misc)[mo3 + img] >> 23) & 0xff, 13, 240);
+                            const int eb3 = ((const int *)misc)[mo3 + 4 + img * L3_META + 9];
+                            r3 = __int_as_float(clampi(eb3 + eb - 126, 1, 254) << 23);
+                        }
                         const unsigned char *tabp = smb + XTAB + img * XTABIMG + (ky * 17 + kx + 8 * half) * 8;
                         const unsigned char *Tr = (const unsigned char *)Tw;
 #pragma unroll
@@ -836,7 +889,8 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                                 const int offs = __float_as_int(e[1]);
                                 const float *g = (const float *)(Tr + (offs & 0xffff));
                                 const float *h3 = (const float *)((const unsigned char *)(T3w + l31) + (offs >> 16));
-                                const float v0 = g[0] + h3[0], v1 = g[32] + h3[32];
+                                const float v0 = WINO ? fmaf(h3[0], r3, g[0]) : g[0] + h3[0];
+                                const float v1 = WINO ? fmaf(h3[32], r3, g[32]) : g[32] + h3[32];
                                 if (t == 0) { acc00[r] = fmaf(e[0], v0, acc00[r]); acc01[r] = fmaf(e[0], v1, acc01[r]); }
                                 else        { acc10[r] = fmaf(e[0], v0, acc10[r]); acc11[r] = fmaf(e[0], v1, acc11[r]); }
                                 if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // four rows in flight, not all 32
@@ -845,6 +899,7 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
 #else
                     acc00 += t0; acc01 += t1;
 #endif
+                    if (it + 1 < 18) { XT3_ISSUE(it + 1) }
                     XPB_F(stagger, grp)
                     XTL(6)
                 }
@@ -923,8 +978,6 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                     for (int k = 0; k < 11; ++k) gn1[im][k] = zf;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) gn2[im][k] = zf;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) gn3[im][k] = zf;
                 }
             }
             // item = K chunk of 32 channels: lane = (tile, 8 channels), two passes of 4 channels; a lane's 8 values of a
@@ -1222,6 +1275,8 @@ static void channel_exponents(const float *w, int rows, int per_row, int *t) {
     }
 }
 
+void conv1_channel_exponents(const float *conv1_w, int *t1) { channel_exponents(conv1_w, 512, 518 * 9, t1); }
+
 void pack_h2_weights(const float *conv1_w, const float *conv2_w, float *wx1, float *wx2, int *t1, int *t2) {
     uint16_t *d1 = (uint16_t *)wx1, *d2 = (uint16_t *)wx2;
     channel_exponents(conv1_w, 512, 518 * 9, t1);
@@ -1282,6 +1337,33 @@ void pack_h2_weights(const float *conv1_w, const float *conv2_w, float *wx1, flo
                         const int n = 64 * w + 32 * u + (lane & 31);
                         const int ch = chunk * 128 + sin * 16 + 8 * (lane >> 5) + j;
                         putn(d2, base, lane, j, W2(n, ch, tap));
+                    }
+            }
+        }
+}
+
+// FP16X2W: conv1's stream without level 3 (regress_l3.hip multiplies it for all proposals at once): per wave 4 slabs of level
+// 0, then per (tap, image) step 4 slabs of level 1 and 4 of level 2 -- waves 0-3 in that order, waves 4-7 level 2 first.
+// Unit layout and the K of a slab as in pack_h2_weights / split_conv1_index; t1 = that function's channel exponents.
+void pack_h2w_conv1(const float *conv1_w, const int *t1, float *wx) {
+    uint16_t *d = (uint16_t *)wx;
+    auto W1 = [&](int n, int ch, int tap) { return std::ldexp(conv1_w[((size_t)n * 518 + ch) * 9 + tap], t1[n]); };
+    for (int w = 0; w < 8; ++w)
+        for (int pos = 0; pos < S1W_SLABS; ++pos) {
+            int slab = pos;                  // canonical numbering of split_conv1_index: per step 0-3 level 1, 4-7 level 2
+            if (pos >= 4) {
+                const int step = (pos - 4) / 8, j = (pos - 4) % 8;
+                const int canon = (w >= 4) ? ((j < 4) ? 4 + j : j - 4) : j;
+                slab = 4 + step * 16 + canon;
+            }
+            for (int u = 0; u < 2; ++u) {
+                const size_t base = ((size_t)w * (S1W_UNITS + XPF) + pos * 2 + u) * (XNPL * 64);
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int n = 64 * w + 32 * u + (lane & 31);
+                        int ch, tap;
+                        split_conv1_index(slab, lane >> 5, j, ch, tap);
+                        putn(d, base, lane, j, (ch < 0) ? 0.f : W1(n, ch, tap));
                     }
             }
         }
