@@ -617,7 +617,7 @@ static int regress_batch_impl(const p2p_regressor *reg1, const p2p_regressor *re
         if (n > 0) {
             int st;
             a.wU = nullptr; a.hinv = nullptr; a.lvl0 = 0; a.p0 = 0; a.p1 = n; a.mblocks = 0;
-            a.l3meta = nullptr; a.l3T = nullptr; a.l3c0 = 0;
+            a.patches = nullptr; a.l3T = nullptr; a.l3c0 = 0;
             if (reg1->mode == P2P_REGRESS_FP16X2W) {
                 st = launch_regress_wino(a, n, (hipStream_t)stream);
             } else if (reg1->mode == P2P_REGRESS_FP16X2) {

@@ -41,8 +41,10 @@ struct RegressArgs {
     unsigned char *wU;
     float *hinv;
     int lvl0, p0, p1, mblocks;
-    // the level-3 part of conv1 comes from regress_l3.hip: metadata and T3 of the round that starts at compact proposal l3c0
-    const float *l3meta, *l3T;
+    // prepared by other launches for the round that starts at compact proposal l3c0: the gathered + normalised patches
+    // (patch_prep_kernel, regress_h2.hip: PI_STRIDE bytes each) and the level-3 part of conv1 (l3_gemm_kernel, regress_l3.hip)
+    const unsigned char *patches;
+    const float *l3T;
     int l3c0;
 };
 
@@ -80,20 +82,21 @@ static inline size_t wino_chunk_rows(size_t n) {        // rows of the transform
     return (std::min(n, (size_t)WINO_CHUNK) + 7) & ~size_t(7);
 }
 static inline size_t wino_u_offset_floats(size_t n) { return (wino_hinv_offset_floats(n) + wino_chunk_rows(n) + 63) & ~size_t(63); }
-// level 3 of conv1 as batched GEMMs (regress_l3.hip), at most L3_CHUNK proposals per round:
-//   meta [c][img 2][12]: sum of squares of the 9 gathered level-3 cells (the per-pixel L2 scale needs them), [9] = the biased
-//        exponent of the largest gathered magnitude (int bits): the rows are scaled by 2^(138 - that) into [2^11, 2^12)
-//   A3   [img 2][row block][K chunk 4][WINO_BLK]: rows 9 c + cell, 128 channels, two fp16 planes, in the LDS image of the GEMM
+// Rounds of at most L3_CHUNK proposals; per round, before the conv1 launches:
+//   patches [c][PI_STRIDE bytes]: the gathered, L2-normalised patch of every proposal as the byte image of the LDS regions conv1
+//        reads (patch_prep_kernel, regress_h2.hip)
+//   A3   [img 2][row block][K chunk 4][WINO_BLK]: the level-3 cells as GEMM rows 9 c + cell, 128 channels, two fp16 planes,
+//        scaled per (proposal, image) by 2^(138 - biased exponent of the largest magnitude), in the LDS image of l3_gemm_kernel
 //   T3   [c][step = tap * 2 + img][wave 8][cell 9][64 n] fp32: what wave `wave` of regress_h2_kernel<true> folds in step `step`
 constexpr int L3_CHUNK = 8192;          // T3 of a round <= 2.7 GB (byte offsets stay below 2^32)
-constexpr int L3_META = 12;
+constexpr int PI_STRIDE = 89088;        // bytes per prepared patch (layout: regress_h2.hip)
 constexpr size_t L3_T3_FLOATS = (size_t)18 * 8 * 9 * 64;      // per proposal: 331 776 bytes
 static inline size_t l3_rows(size_t n) { return std::min(n, (size_t)L3_CHUNK); }
 static inline size_t l3_rowblocks(size_t n) { return (9 * l3_rows(n) + 127) / 128; }
-static inline size_t l3_meta_offset_floats(size_t n) {
+static inline size_t pi_offset_floats(size_t n) {
     return (wino_u_offset_floats(n) + (size_t)16 * (wino_chunk_rows(n) / 8) * 16 * (WINO_BLK / 4) + 63) & ~size_t(63);
 }
-static inline size_t l3_a_offset_floats(size_t n) { return (l3_meta_offset_floats(n) + l3_rows(n) * 2 * L3_META + 63) & ~size_t(63); }
+static inline size_t l3_a_offset_floats(size_t n) { return (pi_offset_floats(n) + l3_rows(n) * (PI_STRIDE / 4) + 63) & ~size_t(63); }
 static inline size_t l3_t_offset_floats(size_t n) { return l3_a_offset_floats(n) + 2 * l3_rowblocks(n) * 4 * (WINO_BLK / 4); }
 static inline size_t regress_ws_floats(size_t n) { return l3_t_offset_floats(n) + l3_rows(n) * L3_T3_FLOATS; }
 
@@ -385,7 +388,9 @@ void pack_h2w_conv1(const float *conv1_w, const int *t1, float *wh1w);          
 // GEMMs (tap, image) over the cells of ALL proposals; filter blocks [img 2][tap 9][column block 4][K chunk 4][WINO_BLK]
 constexpr size_t WL3_FLOATS = (size_t)2 * 9 * 4 * 4 * (WINO_BLK / 4);
 void pack_l3_weights(const float *conv1_w, const int *t1, float *wl3);            // host
-int launch_regress_l3(const RegressArgs &a, int c0, int c1, float *meta, unsigned char *A3, float *T3, hipStream_t stream);
+int launch_regress_l3(const RegressArgs &a, int c0, int c1, const unsigned char *A3, float *T3, hipStream_t stream);
+// regress_h2.hip: the patches (and the level-3 GEMM rows) of the compact proposals [c0, c1) of level a.lvl0
+int launch_patch_prep(const RegressArgs &a, int c0, int c1, unsigned char *patches, unsigned char *A3, hipStream_t stream);
 
 // regress_wino.hip: conv2 as Winograd F(2x2, 3x3) GEMMs; filter blocks [position 16][column block 4][K chunk 16][WINO_BLK]
 constexpr size_t WW2_FLOATS = (size_t)16 * 4 * 16 * (WINO_BLK / 4);

@@ -11,10 +11,9 @@
 // proposals through LDS (tiles filled 16 / 16); regress_h2_kernel<true> reads its T3 rows from global memory instead
 // (331 776 bytes per proposal and level, written once, read once).
 //
-//   l3_prep_kernel    one wave per (proposal, image): gathers the 3 x 3 x 128 level-3 values exactly like
-//                     select_local_patch_feats does (same clamps), leaves per cell the sum of squares (a term of the per-pixel
-//                     L2 norm, networks/patch2pix.py:173-174) and the exponent of the largest magnitude, and writes the cells
-//                     x 2^(138 - exponent) (largest value in [2^11, 2^12)) as two fp16 planes into the A blocks of the GEMM
+//   patch_prep_kernel (regress_h2.hip) gathers the 3 x 3 x 128 level-3 values of every (proposal, image) exactly like
+//                     select_local_patch_feats does (same clamps) and writes the cells x 2^(138 - biased exponent of the largest
+//                     magnitude) (largest value in [2^11, 2^12)) as two fp16 planes into the A blocks of the GEMM
 //                     (row = 9 * proposal + cell), in the block layout that IS the LDS image (regress_wino.hip header).
 //   l3_gemm_kernel    work-group = 128 rows x one image x three taps x all 512 outputs: the A rows (K = 128: 64 KB) stay in
 //                     LDS, the filters stream through a ring of four 16 KB LDS-DMA stages (three in flight, counted vmcnt
@@ -31,115 +30,7 @@
 namespace p2p {
 
 typedef _Float16 le8 __attribute__((ext_vector_type(8)));
-typedef _Float16 le2 __attribute__((ext_vector_type(2)));
-typedef float lf2 __attribute__((ext_vector_type(2)));
 #define LMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(le8, (a)), __builtin_bit_cast(le8, (b)), (c), 0, 0, 0)
-
-struct L3PrepArgs {
-    float *meta;                 // [cn][img 2][L3_META]
-    unsigned char *A3;           // [img 2][rowblocks][K chunk 4][WINO_BLK]
-    int c0, cn, rowblocks, lvl;
-};
-
-__device__ __forceinline__ unsigned l3_pk(float a, float b) {
-    const lf2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, le2));
-}
-__device__ __forceinline__ float l3_lo(unsigned h) { return (float)__builtin_bit_cast(le2, h)[0]; }
-__device__ __forceinline__ float l3_hi(unsigned h) { return (float)__builtin_bit_cast(le2, h)[1]; }
-
-__global__ __launch_bounds__(64) void l3_prep_kernel(RegressArgs args, L3PrepArgs x) {
-    __shared__ __attribute__((aligned(16))) float cells[9 * 128];
-    const int lane = threadIdx.x, img = blockIdx.y, cl = blockIdx.x;
-    const int slot = (cl < x.cn) ? wino_slot(args, x.c0 + cl) : -1;
-    // the 16-byte pieces of this block's 9 rows: item = (cell, piece of 8 channels), 144 of them
-    auto piece_ptr = [&](int it) {
-        const int cell = it >> 4, piece = it & 15;
-        const unsigned R = (unsigned)cl * 9u + (unsigned)cell, rb = R >> 7, r = R & 127u;
-        const unsigned kc = (unsigned)piece >> 2, q = (unsigned)piece & 3u;
-        return (rb < (unsigned)x.rowblocks)
-                   ? x.A3 + ((size_t)((unsigned)img * (unsigned)x.rowblocks + rb) * 4 + kc) * WINO_BLK + (r * 4u + (q ^ ((r >> 2) & 3u))) * 16u
-                   : (unsigned char *)nullptr;
-    };
-    if (slot < 0) {      // no such proposal: its rows (inside the allocated row blocks) are zeros, never uninitialised memory
-        for (int it = lane; it < 144; it += 64) {
-            unsigned char *d = piece_ptr(it);
-            if (d) {
-                *(uint4 *)d = make_uint4(0u, 0u, 0u, 0u);
-                *(uint4 *)(d + WINO_BLK / 2) = make_uint4(0u, 0u, 0u, 0u);
-            }
-        }
-        return;
-    }
-    int it = 0;
-    while (it + 1 < args.nitems && slot >= args.start[it + 1]) ++it;
-    const ItemDev &I = args.item[it];
-    // the window origin of this image (networks/utils.py:8-19: x, y = imatches.long(), window [-8, 7])
-    float vx, vy;
-    if (x.lvl > 0) {
-        const float *np = args.ws + ((2 * (size_t)args.n * 512 + 31) & ~(size_t)31) + (size_t)slot * 4 + 2 * img;
-        vx = np[0]; vy = np[1];
-    } else if (args.is_float) {
-        const float *pp = (const float *)args.proposals + (size_t)slot * 4 + 2 * img;
-        vx = pp[0]; vy = pp[1];
-    } else {
-        const long long *pp = (const long long *)args.proposals + (size_t)slot * 4 + 2 * img;
-        vx = (float)pp[0]; vy = (float)pp[1];
-    }
-    const int x0 = (int)vx - 8, y0 = (int)vy - 8;
-    const int Hh = I.H[img], Ww = I.W[img];
-    const int Hj = Hh >> 3, Wj = Ww >> 3;                         // index clamp: dim // ds (networks/utils.py:22-23)
-    const int Ha = level_dim(Hh, 3), Wa = level_dim(Ww, 3);       // extent of the backbone's map
-    const int r0 = clampi(y0 >> 3, 0, Hj - 1), c0 = clampi(x0 >> 3, 0, Wj - 1);
-    const float *src = I.pyr[img][3];
-    float v[2][9];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int ch = lane + 64 * k;
-#pragma unroll
-        for (int cell = 0; cell < 9; ++cell)
-            v[k][cell] = src[((size_t)ch * Ha + min(r0 + cell / 3, Hj - 1)) * Wa + min(c0 + cell % 3, Wj - 1)];
-    }
-    float mx = 0.f, ss[9];
-#pragma unroll
-    for (int cell = 0; cell < 9; ++cell) {
-        cells[cell * 128 + lane] = v[0][cell];
-        cells[cell * 128 + lane + 64] = v[1][cell];
-        ss[cell] = fmaf(v[1][cell], v[1][cell], v[0][cell] * v[0][cell]);
-        mx = fmaxf(mx, fmaxf(fabsf(v[0][cell]), fabsf(v[1][cell])));
-    }
-    // fixed butterfly: the same sums whatever the launch
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-#pragma unroll
-        for (int cell = 0; cell < 9; ++cell) ss[cell] += __shfl_xor(ss[cell], m);
-        mx = fmaxf(mx, __shfl_xor(mx, m));
-    }
-    const int eb3 = clampi((__float_as_int(mx) >> 23) & 0xff, 20, 250);
-    const float mul = __int_as_float((265 - eb3) << 23);          // largest magnitude -> [2^11, 2^12)
-    float *meta = x.meta + ((size_t)cl * 2 + img) * L3_META;
-#pragma unroll
-    for (int cell = 0; cell < 9; ++cell)
-        if (lane == cell) meta[cell] = ss[cell];
-    if (lane == 9) meta[9] = __int_as_float(eb3);
-    __syncthreads();
-    for (int it2 = lane; it2 < 144; it2 += 64) {
-        unsigned char *d = piece_ptr(it2);
-        const float *p = cells + (it2 >> 4) * 128 + (it2 & 15) * 8;
-        const f32x4 a = *(const f32x4 *)p, b = *(const f32x4 *)(p + 4);
-        const float w[8] = {a[0] * mul, a[1] * mul, a[2] * mul, a[3] * mul, b[0] * mul, b[1] * mul, b[2] * mul, b[3] * mul};
-        unsigned h0[4], h1[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            h0[q] = l3_pk(w[2 * q], w[2 * q + 1]);
-            h1[q] = l3_pk(w[2 * q] - l3_lo(h0[q]), w[2 * q + 1] - l3_hi(h0[q]));
-        }
-        if (d) {
-            *(uint4 *)d = make_uint4(h0[0], h0[1], h0[2], h0[3]);
-            *(uint4 *)(d + WINO_BLK / 2) = make_uint4(h1[0], h1[1], h1[2], h1[3]);
-        }
-    }
-}
 
 // --------------------------------------------------------------------------------------------------
 constexpr int LNT = 512;                 // 8 waves, two per SIMD
@@ -300,7 +191,7 @@ void pack_l3_weights(const float *conv1_w, const int *t1, float *out) {
 }
 
 // T3 (and the metadata) of the compact proposals [c0, c1) of level a.lvl0
-int launch_regress_l3(const RegressArgs &a, int c0, int c1, float *meta, unsigned char *A3, float *T3, hipStream_t stream) {
+int launch_regress_l3(const RegressArgs &a, int c0, int c1, const unsigned char *A3, float *T3, hipStream_t stream) {
     int dev = 0;
     P2P_HIP_CHECK(hipGetDevice(&dev));
     static bool attr_set[64] = {false};          // (idempotent per device; see the threading note of include/p2p_hip.h)
@@ -311,12 +202,6 @@ int launch_regress_l3(const RegressArgs &a, int c0, int c1, float *meta, unsigne
     const int cn = c1 - c0;
     if (cn <= 0) return P2P_OK;
     const int rowblocks = (9 * cn + 127) / 128;
-    L3PrepArgs x;
-    x.meta = meta; x.A3 = A3; x.c0 = c0; x.cn = cn; x.rowblocks = rowblocks; x.lvl = a.lvl0;
-    // every row of the allocated row blocks is written: proposals beyond cn (the tail of the last block) as zeros
-    hipLaunchKernelGGL(l3_prep_kernel, dim3((rowblocks * 128 + 8) / 9, 2), dim3(64), 0, stream, a, x);
-    int st = check_launch("l3_prep_kernel");
-    if (st != P2P_OK) return st;
     L3GemmArgs g;
     g.A3 = A3; g.W = (const unsigned char *)a.reg[a.lvl0].wl3; g.T3 = T3; g.rowblocks = rowblocks; g.cn = cn; g.c0 = c0;
     g.dev_counts = a.dev_counts; g.nitems = a.nitems; g.n = a.n;

@@ -267,17 +267,20 @@ int launch_regress_wino(RegressArgs a, int n, hipStream_t stream) {
     P2P_REQUIRE(a.ws, P2P_EINVAL, "%s: the scratch buffer is missing", "launch_regress_wino");
     unsigned char *wsU = (unsigned char *)(a.ws + wino_u_offset_floats((size_t)n));
     float *hinv = a.ws + wino_hinv_offset_floats((size_t)n);
-    float *meta = a.ws + l3_meta_offset_floats((size_t)n), *T3 = a.ws + l3_t_offset_floats((size_t)n);
+    float *T3 = a.ws + l3_t_offset_floats((size_t)n);
     unsigned char *A3 = (unsigned char *)(a.ws + l3_a_offset_floats((size_t)n));
+    unsigned char *patches = (unsigned char *)(a.ws + pi_offset_floats((size_t)n));
     for (int lvl = 0; lvl < a.nlevels; ++lvl) {
         a.lvl0 = lvl;
-        // rounds of at most L3_CHUNK proposals: level 3 of conv1 for the whole round (regress_l3.hip: gather + 18 GEMMs -> T3),
+        // rounds of at most L3_CHUNK proposals: the patches of the whole round (patch_prep_kernel) and level 3 of conv1 (18 GEMMs -> T3),
         // then chunk by chunk conv1 -> transformed conv2 input (regress_h2_kernel<true>) and the Winograd GEMMs (-> V)
         for (int l0 = 0; l0 < n; l0 += L3_CHUNK) {
             const int l1 = std::min(n, l0 + L3_CHUNK);
-            int st = launch_regress_l3(a, l0, l1, meta, A3, T3, stream);
+            int st = launch_patch_prep(a, l0, l1, patches, A3, stream);
             if (st != P2P_OK) return st;
-            a.l3meta = meta; a.l3T = T3; a.l3c0 = l0;
+            st = launch_regress_l3(a, l0, l1, A3, T3, stream);
+            if (st != P2P_OK) return st;
+            a.patches = patches; a.l3T = T3; a.l3c0 = l0;
             for (int ch = 0, nch = wino_nchunks((size_t)(l1 - l0)); ch < nch; ++ch) {
                 int p0, p1;
                 wino_chunk_range((size_t)(l1 - l0), ch, &p0, &p1);
