@@ -53,7 +53,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 MODES = {
     "fp16x2w": dict(kernel="p2p_regress_batch", products=3, peak=PEAK_BF16_MFMA_TFLOPS / 3.0,
-                    kernels=["l3_prep_kernel", "l3_gemm_kernel", "regress_h2_kernel<true>", "wino_gemm_kernel", "regress_fc_kernel"],
+                    kernels=["regress_h2_kernel<true>", "wino_gemm_kernel", "regress_fc_kernel"],
                     dtype="f32-equivalent: fp16x2 (every f32 operand, scaled by an exact power of two, = sum of 2 fp16 planes to within "
                           "2^-24 of its magnitude; 3 fp16 MFMA products per f32 product, f32 accumulate); second convolution as "
                           "Winograd F(2x2,3x3) (transforms in f32, filters transformed in f64)",
@@ -335,10 +335,9 @@ def roofline_of(mode, events):
                                      "DESIGN.md section 4)")
     if "kernels" in M:
         out["kernels"] = M["kernels"]
-        out["note"] = ("the fine stage of one step = ONE p2p_regress_batch call = per regressor level l3_prep_kernel + l3_gemm_kernel "
-                       "(level 3 of conv1 as 18 batched GEMMs over the cells of all proposals), then per chunk of <= 2560 proposals "
-                       "regress_h2_kernel<true> (gather + conv1 levels 0-2 + fold -> transformed conv2 input) and wino_gemm_kernel "
-                       "(conv2 as 16 batched GEMMs + BN + max-pool), then regress_fc_kernel; achieved = algorithmic flop of the call "
+        out["note"] = ("the fine stage of one step = ONE p2p_regress_batch call = per regressor level and chunk of <= 2560 proposals "
+                       "regress_h2_kernel<true> (gather + conv1 -> transformed conv2 input) and wino_gemm_kernel (conv2 as 16 "
+                       "batched GEMMs + BN + max-pool), then regress_fc_kernel per level; achieved = algorithmic flop of the call "
                        "(608.3 MFLOP x proposals x levels) / its duration between HIP events on the launch stream = the sum of "
                        "its kernels in the rocprofv3 summary")
     return out

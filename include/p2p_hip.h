@@ -200,7 +200,9 @@ typedef struct p2p_pyramid {
  *               outside the call)                                                             */
 size_t p2p_regress_workspace_bytes(int n);
 /* The same for ONE arithmetic mode (p2p_regress_workspace_bytes is the largest of them = the default mode's):
- * P2P_REGRESS_FP16X2W  4 KB per proposal slot + 512 KiB per proposal of a chunk of at most 2048 (<= 1.07 GB),
+ * P2P_REGRESS_FP16X2W  4 KB per proposal slot + 512 KiB per proposal of a chunk of at most 2560 (<= 1.34 GB: the value
+ *                      jumps from ~2 MB per proposal to that cap once n exceeds one chunk -- callers that run another
+ *                      mode should size their buffer with this query, not with p2p_regress_workspace_bytes),
  * P2P_REGRESS_FP16X2   4 KB per proposal slot,   P2P_REGRESS_F32   0 (the buffer is ignored).                      */
 size_t p2p_regress_workspace_bytes_mode(int n, int mode);
 int p2p_regress(const p2p_regressor *reg1, const p2p_regressor *reg2,

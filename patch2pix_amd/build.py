@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["api.hip", "backbone.hip", "coarse.hip", "consensus.hip", "filter.hip", "regress.hip", "regress_h2.hip", "regress_wino.hip", "regress_l3.hip"]
+SOURCES = ["api.hip", "backbone.hip", "coarse.hip", "consensus.hip", "filter.hip", "regress.hip", "regress_h2.hip", "regress_wino.hip"]
 LIB = os.path.join(CSRC, "libp2p_hip.so")
 
 

@@ -14,7 +14,7 @@
 #if !defined(P2P_EXPERIMENT) &&                                                                                          \
     (defined(XF_PIN_W) || defined(XF_SAME_PATCH) || defined(XF_SKIP_P) || defined(XF_SKIP_C) || defined(XF_SKIP_FOLD) ||   \
      defined(XF_SKIP_CONV2) || defined(XF_CONV2_HALF) || defined(XF_SKIP_FC) || defined(XF_GRID_CAP) || defined(XF_TURN4) || \
-     defined(XF_WINO_NOSTORE) || defined(XF_WINO_NT) || defined(XF_WINO_STAGGER) || defined(P2P_WINO_CHUNK) || defined(XF_WINO_NOXF) || defined(XF_WINO_NOFOLD) || defined(XF_WINO_NODMA) || defined(XF_T3_SAME) || defined(XF_T3_NODMA) ||          \
+     defined(XF_WINO_NOSTORE) || defined(XF_WINO_NT) || defined(XF_WINO_STAGGER) || defined(P2P_WINO_CHUNK) || defined(XF_WINO_NOXF) || defined(XF_WINO_NOFOLD) || defined(XF_WINO_NODMA) ||           \
      defined(P2P_X3_TIMING) || defined(NCF_TIMING) || defined(XF_TURNS1) || defined(XF_TURNS2) || defined(XP_VALU) || defined(XH_BURST) ||       \
      defined(XH_NOSNAKE))
 #error "experiment switches (XF_*, XH_*, XP_*, P2P_X3_TIMING, NCF_TIMING, P2P_WINO_CHUNK) need -DP2P_EXPERIMENT: the library then identifies itself as an experiment build"
@@ -119,7 +119,6 @@ struct p2p_regressor {
     const float *wh1, *wh2;     // fp16x2: the same weights, scaled per output channel, split into two fp16 planes
     const float *bn1s_h, *bn2s_h;   // fp16x2: folded BN scales times the inverse of those weight (and activation) scales
     const float *ww2, *bn2s_w;      // fp16x2w: conv2 as Winograd-transformed filter blocks (regress_wino.hip) + its BN scale
-    const float *wh1w, *wl3, *bn1s_w;   // fp16x2w: conv1's stream without level 3, level 3 as GEMM blocks (regress_l3.hip), BN1 scale
     int mode;                   // P2P_REGRESS_F32 | P2P_REGRESS_FP16X2 | P2P_REGRESS_FP16X2W
     const float *bn1s, *bn1b;   // folded BN scale/shift [512]
     const float *bn2s, *bn2b;   // [512]

@@ -365,21 +365,16 @@ static int ensure_mode(p2p_regressor *r, int mode) {
     auto al = [](size_t n) { return (n + 63) & ~size_t(63); };
     const float *c1 = r->conv1_w.data(), *c2 = r->conv2_w.data();
     if (mode == P2P_REGRESS_FP16X2W && !r->dev_w) {
-        // conv2 as Winograd filter blocks; conv1 as its own stream without level 3 + level 3 as GEMM blocks (regress_l3.hip);
-        // the direct fp16x2 streams are NOT packed for this mode
-        const size_t ob2 = al(WW2_FLOATS), o1w = ob2 + 512, ol3 = o1w + al(WH1W_FLOATS), ob1 = ol3 + al(WL3_FLOATS);
-        std::vector<float> h(ob1 + 512, 0.f);
-        std::vector<int> t1(512), t2(512);
+        const int st0 = ensure_mode(r, P2P_REGRESS_FP16X2);      // conv1 runs from the fp16x2 stream
+        if (st0 != P2P_OK) return st0;
+        const size_t ob2 = al(WW2_FLOATS);
+        std::vector<float> h(ob2 + 512, 0.f);
+        std::vector<int> t2(512);
         pack_wino_weights(c2, &h[0], t2.data());
         for (int n = 0; n < 512; ++n) h[ob2 + n] = std::ldexp(r->bn2s_host[n], -t2[n]);
-        conv1_channel_exponents(c1, t1.data());
-        pack_h2w_conv1(c1, t1.data(), &h[o1w]);
-        pack_l3_weights(c1, t1.data(), &h[ol3]);
-        // conv1 accumulates 2^12 (activations) x 2^t1[n] (weights) x the true sum, as in the direct mode
-        for (int n = 0; n < 512; ++n) h[ob1 + n] = std::ldexp(r->bn1s_host[n], -12 - t1[n]);
-        const int st = upload(h, &r->dev_w, "the Winograd filter blocks and the conv1 streams of the fp16x2w mode");
+        const int st = upload(h, &r->dev_w, "the Winograd filter blocks");
         if (st != P2P_OK) return st;
-        r->ww2 = r->dev_w; r->bn2s_w = r->dev_w + ob2; r->wh1w = r->dev_w + o1w; r->wl3 = r->dev_w + ol3; r->bn1s_w = r->dev_w + ob1;
+        r->ww2 = r->dev_w; r->bn2s_w = r->dev_w + ob2;
     } else if (mode == P2P_REGRESS_FP16X2 && !r->dev_h) {
         const size_t o1 = 0, o2 = al(WH1_FLOATS), ob1 = o2 + al(WH2_FLOATS), ob2 = ob1 + 512;
         std::vector<float> h(ob2 + 512, 0.f);
@@ -490,7 +485,7 @@ extern "C" int p2p_regressor_create(const p2p_regressor_params *p, p2p_regressor
     (void)hipGetDevice(&r->device);
     r->dev = dev;
     r->dev_p = r->dev_h = r->dev_w = nullptr;
-    r->ww2 = r->bn2s_w = r->wp1 = r->wp2 = r->wh1 = r->wh2 = r->bn1s_h = r->bn2s_h = r->wh1w = r->wl3 = r->bn1s_w = nullptr;
+    r->ww2 = r->bn2s_w = r->wp1 = r->wp2 = r->wh1 = r->wh2 = r->bn1s_h = r->bn2s_h = nullptr;
     r->conv1_w.assign(p->conv1_w, p->conv1_w + (size_t)512 * 518 * 9);      // host copies: another mode's stream is packed on demand
     r->conv2_w.assign(p->conv2_w, p->conv2_w + (size_t)512 * 512 * 9);
     r->bn1s_host.assign(&h[o_bn1s], &h[o_bn1s] + 512);
@@ -526,8 +521,6 @@ static RegDev to_dev(const p2p_regressor *r) {
     d.fc1t = r->fc1t; d.fc1b = r->fc1b; d.bnf1s = r->bnf1s; d.bnf1b = r->bnf1b;
     d.fc2t = r->fc2t; d.fc2b = r->fc2b; d.bnf2s = r->bnf2s; d.bnf2b = r->bnf2b; d.fc3 = r->fc3; d.fc3b = r->fc3b;
     d.fc1p = r->fc1p; d.fc2p = r->fc2p;
-    d.wh1w = r->wh1w; d.wl3 = r->wl3;
-    if (r->mode == P2P_REGRESS_FP16X2W) d.bn1s_h = r->bn1s_w;      // the same fold as the direct mode's, from this mode's allocation
     return d;
 }
 
@@ -617,7 +610,6 @@ static int regress_batch_impl(const p2p_regressor *reg1, const p2p_regressor *re
         if (n > 0) {
             int st;
             a.wU = nullptr; a.hinv = nullptr; a.lvl0 = 0; a.p0 = 0; a.p1 = n; a.mblocks = 0;
-            a.patches = nullptr; a.l3T = nullptr; a.l3c0 = 0;
             if (reg1->mode == P2P_REGRESS_FP16X2W) {
                 st = launch_regress_wino(a, n, (hipStream_t)stream);
             } else if (reg1->mode == P2P_REGRESS_FP16X2) {

@@ -17,7 +17,6 @@ struct RegDev {
     const float *fc1t, *fc1b, *bnf1s, *bnf1b, *fc2t, *fc2b, *bnf2s, *bnf2b, *fc3, *fc3b;
     const float *fc1p, *fc2p;           // fc1 / fc2 in v_mfma_f32_16x16x4_f32 fragment order (fc_batch_parse)
     const float *ww2, *bn2s_w;          // conv2 as Winograd-transformed filter blocks + its BN scale (regress_wino.hip)
-    const float *wh1w, *wl3;            // FP16X2W: conv1's weight stream without level 3; level 3 as GEMM blocks (regress_l3.hip)
 };
 
 struct ItemDev {
@@ -41,20 +40,14 @@ struct RegressArgs {
     unsigned char *wU;
     float *hinv;
     int lvl0, p0, p1, mblocks;
-    // prepared by other launches for the round that starts at compact proposal l3c0: the gathered + normalised patches
-    // (patch_prep_kernel, regress_h2.hip: PI_STRIDE bytes each) and the level-3 part of conv1 (l3_gemm_kernel, regress_l3.hip)
-    const unsigned char *patches;
-    const float *l3T;
-    int l3c0;
 };
 
 // scratch of the kernels whose FC tail is batched over a work-group's proposals (regress_h2.hip): the pooled
 // convolution features V [level][n][512] and the un-truncated mid matches [n][4] the fine level starts from
 constexpr int FC_ROWS = 16;             // proposals per FC batch = rows of a v_mfma_f32_16x16x4_f32 tile
-// P2P_REGRESS_FP16X2W appends: the inverse H scale per proposal of a chunk, and the transformed conv2 input of a chunk of
-// proposals (16 positions x 16 tiles x 512 channels x 2 fp16 planes = 512 KiB per proposal), as the A
-// blocks of wino_gemm_kernel: [position 16][row block of 8 proposals][K chunk 16][WINO_BLK bytes]; then the level-3 part of
-// conv1 (regress_l3.hip): per-proposal metadata, the gathered level-3 cells as GEMM rows, and the GEMM's output T3
+// P2P_REGRESS_FP16X2W appends: the inverse H scale per proposal of a chunk, and the transformed conv2 input of a chunk of at
+// most WINO_CHUNK (2560) proposals (16 positions x 16 tiles x 512 channels x 2 fp16 planes = 512 KiB per proposal), as the A
+// blocks of wino_gemm_kernel: [position 16][row block of 8 proposals][K chunk 16][WINO_BLK bytes]
 constexpr int WINO_BLK = 16384;         // [plane 2][row 128][32 K] fp16
 #ifndef P2P_WINO_CHUNK
 #define P2P_WINO_CHUNK 2560
@@ -62,7 +55,7 @@ constexpr int WINO_BLK = 16384;         // [plane 2][row 128][32 K] fp16
 // Proposals per conv1 -> GEMM round.  A call's n proposals are cut into ceil(units / (WINO_CHUNK / 256)) chunks of whole
 // units of 256 proposals (= whole rounds of the persistent conv1 launch on 256 compute units, two rounds of the GEMM's
 // 128-row x 128-column work-groups), sizes as even as the units allow: 6400 -> 2304 + 2048 + 2048 (a fixed chunk of 2048
-// left a last launch of 256 proposals = half-empty GEMM round and a full set of fixed per-launch costs).
+// left a last launch of 256 proposals = a half-empty GEMM round and a full set of fixed per-launch costs).
 constexpr int WINO_CHUNK = P2P_WINO_CHUNK;
 static_assert(WINO_CHUNK % 256 == 0 && WINO_CHUNK >= 256, "chunks are whole units of 256 proposals");
 static inline int wino_nchunks(size_t n) {
@@ -78,27 +71,13 @@ static inline void wino_chunk_range(size_t n, int c, int *p0, int *p1) {
 }
 static inline size_t regress_ws_base_floats(size_t n) { return ((2 * n * 512 + 31) & ~size_t(31)) + 4 * n + 32; }
 static inline size_t wino_hinv_offset_floats(size_t n) { return (regress_ws_base_floats(n) + 63) & ~size_t(63); }
-static inline size_t wino_chunk_rows(size_t n) {        // rows of the transformed-input buffer: no chunk of any round is larger
+static inline size_t wino_chunk_rows(size_t n) {        // rows of the transformed-input buffer: no chunk is larger
     return (std::min(n, (size_t)WINO_CHUNK) + 7) & ~size_t(7);
 }
 static inline size_t wino_u_offset_floats(size_t n) { return (wino_hinv_offset_floats(n) + wino_chunk_rows(n) + 63) & ~size_t(63); }
-// Rounds of at most L3_CHUNK proposals; per round, before the conv1 launches:
-//   patches [c][PI_STRIDE bytes]: the gathered, L2-normalised patch of every proposal as the byte image of the LDS regions conv1
-//        reads (patch_prep_kernel, regress_h2.hip)
-//   A3   [img 2][row block][K chunk 4][WINO_BLK]: the level-3 cells as GEMM rows 9 c + cell, 128 channels, two fp16 planes,
-//        scaled per (proposal, image) by 2^(138 - biased exponent of the largest magnitude), in the LDS image of l3_gemm_kernel
-//   T3   [c][step = tap * 2 + img][wave 8][cell 9][64 n] fp32: what wave `wave` of regress_h2_kernel<true> folds in step `step`
-constexpr int L3_CHUNK = 8192;          // T3 of a round <= 2.7 GB (byte offsets stay below 2^32)
-constexpr int PI_STRIDE = 89088;        // bytes per prepared patch (layout: regress_h2.hip)
-constexpr size_t L3_T3_FLOATS = (size_t)18 * 8 * 9 * 64;      // per proposal: 331 776 bytes
-static inline size_t l3_rows(size_t n) { return std::min(n, (size_t)L3_CHUNK); }
-static inline size_t l3_rowblocks(size_t n) { return (9 * l3_rows(n) + 127) / 128; }
-static inline size_t pi_offset_floats(size_t n) {
-    return (wino_u_offset_floats(n) + (size_t)16 * (wino_chunk_rows(n) / 8) * 16 * (WINO_BLK / 4) + 63) & ~size_t(63);
+static inline size_t regress_ws_floats(size_t n) {
+    return wino_u_offset_floats(n) + (size_t)16 * (wino_chunk_rows(n) / 8) * 16 * (WINO_BLK / 4);
 }
-static inline size_t l3_a_offset_floats(size_t n) { return (pi_offset_floats(n) + l3_rows(n) * (PI_STRIDE / 4) + 63) & ~size_t(63); }
-static inline size_t l3_t_offset_floats(size_t n) { return l3_a_offset_floats(n) + 2 * l3_rowblocks(n) * 4 * (WINO_BLK / 4); }
-static inline size_t regress_ws_floats(size_t n) { return l3_t_offset_floats(n) + l3_rows(n) * L3_T3_FLOATS; }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -374,23 +353,8 @@ constexpr int XPF = 8;                   // units the weight prefetch may run pa
 constexpr size_t WH1_FLOATS = (size_t)8 * (S1_UNITS + XPF) * 512;
 constexpr size_t WH2_FLOATS = (size_t)8 * (S2_UNITS + XPF) * 512;
 void pack_h2_weights(const float *conv1_w, const float *conv2_w, float *wh1, float *wh2, int *t1, int *t2);      // host
-void conv1_channel_exponents(const float *conv1_w, int *t1);                      // host: the t1 of pack_h2_weights
 int launch_regress_h2(const RegressArgs &a, int n, hipStream_t stream);
 int launch_regress_h2_conv1(const RegressArgs &a, int n, hipStream_t stream);   // conv1 -> transformed conv2 input (FP16X2W)
-// FP16X2W: conv1's stream without the level-3 units: per wave 8 units of level 0, then per (tap, image) step 8 units of level 1
-// (pixel range) and 8 of level 2 (cell range) -- waves 4-7 the cell range first
-constexpr int S1W_SLABS = 4 + 9 * 2 * 8;
-constexpr int S1W_UNITS = 2 * S1W_SLABS;
-constexpr size_t WH1W_FLOATS = (size_t)8 * (S1W_UNITS + XPF) * 512;
-void pack_h2w_conv1(const float *conv1_w, const int *t1, float *wh1w);            // host (t1: the exponents of pack_h2_weights)
-
-// regress_l3.hip: level 3 of conv1 (128 of the 259 channels per image, 3 x 3 distinct cells per image and proposal) as 18
-// GEMMs (tap, image) over the cells of ALL proposals; filter blocks [img 2][tap 9][column block 4][K chunk 4][WINO_BLK]
-constexpr size_t WL3_FLOATS = (size_t)2 * 9 * 4 * 4 * (WINO_BLK / 4);
-void pack_l3_weights(const float *conv1_w, const int *t1, float *wl3);            // host
-int launch_regress_l3(const RegressArgs &a, int c0, int c1, const unsigned char *A3, float *T3, hipStream_t stream);
-// regress_h2.hip: the patches (and the level-3 GEMM rows) of the compact proposals [c0, c1) of level a.lvl0
-int launch_patch_prep(const RegressArgs &a, int c0, int c1, unsigned char *patches, unsigned char *A3, hipStream_t stream);
 
 // regress_wino.hip: conv2 as Winograd F(2x2, 3x3) GEMMs; filter blocks [position 16][column block 4][K chunk 16][WINO_BLK]
 constexpr size_t WW2_FLOATS = (size_t)16 * 4 * 16 * (WINO_BLK / 4);

@@ -137,14 +137,11 @@ constexpr int HST = 128 * 2 + 16, HPL = 66 * HST;                 // 272, 17952
 constexpr int HCHUNK = XNPL * HPL;                                // 35904: planes of chunk c start at c * HCHUNK
 constexpr int XCONV2B = 4 * HCHUNK;
 // both phases, then the FC batch of the level (fc_batch_parse) over the whole allocation
-constexpr int XSM_MISC = (XCONV1B > XCONV2B) ? XCONV1B : XCONV2B;  // [64] floats: 4-7 the next proposal (WINO), 8-11 the proposal,
-                                                                  // 12-14 the fp16 scale reductions (WINO: 12, 13 from the prepared
-                                                                  // patch), 20-21 the level-3 exponents (WINO)
-constexpr int XMISC_FLOATS = 64;
+constexpr int XSM_MISC = (XCONV1B > XCONV2B) ? XCONV1B : XCONV2B;  // [16] floats: 8-11 the proposal, 12-14 the fp16 scale reductions
 #ifdef P2P_X3_TIMING
-constexpr int XSM_BYTES = XSM_MISC + XMISC_FLOATS * 4 + 8 * 16 * 4;
+constexpr int XSM_BYTES = XSM_MISC + 16 * 4 + 8 * 16 * 4;
 #else
-constexpr int XSM_BYTES = XSM_MISC + XMISC_FLOATS * 4;
+constexpr int XSM_BYTES = XSM_MISC + 16 * 4;
 #endif
 static_assert(FC_LDS_BYTES <= XSM_MISC, "the FC batch stages its rows over the convolution buffers");
 static_assert(2 * XTMPIMG <= XSHR && 64 * XA0ST <= XSHR, "the shared region is sized by the fold buffers");
@@ -152,22 +149,6 @@ static_assert(XIMG % 16 == 0 && YOFF2 % 16 == 0 && YOFF3 % 16 == 0 && YPL2 % 16 
               XTAB % 16 == 0 && XSM_SCALE % 16 == 0 && HPL % 16 == 0 && HCHUNK % 16 == 0 && XCONV2B % 16 == 0,
               "16-byte alignment of ds_read_b128");
 static_assert(XSM_BYTES <= 160 * 1024, "LDS budget");
-
-// P2P_REGRESS_FP16X2W: the gathered, normalised patch of a proposal is prepared by patch_prep_kernel (below) for ALL proposals of
-// a round and parked in global memory as the byte image of the LDS regions conv1 reads -- regress_h2_kernel<true> copies it in
-// with a few LDS-DMA instructions instead of running the gather / scale / im2col phases serially on its compute unit:
-//   [img 2][level 1 fp32 grid | level 2 planes]   = LDS [img * XIMG, + YOFF3)
-//   A0 (the pre-scaled level-0 im2col block)      = LDS [XSHARED, + 64 * XA0ST)
-//   fold tables [2][17][17] + 16 B + scale [2][256] = LDS [XTAB, XCONV1B)
-//   meta: float bits of the smallest per-pixel scale [img 2], biased exponent of the largest level-3 magnitude [img 2]
-constexpr int PI_IMG = YOFF3;
-constexpr int PI_A0 = 2 * PI_IMG;
-constexpr int PI_TAB = PI_A0 + 64 * XA0ST;
-constexpr int PI_TABBYTES = 2 * XTABIMG + 16 + 2 * 256 * 4;
-constexpr int PI_META = PI_TAB + PI_TABBYTES;
-static_assert(PI_STRIDE >= PI_META + 64 && PI_STRIDE % 256 == 0, "regress_common.h: PI_STRIDE");
-static_assert(PI_IMG % 16 == 0 && PI_A0 % 16 == 0 && PI_TAB % 16 == 0 && PI_TABBYTES % 16 == 0 && XTAB + PI_TABBYTES == XCONV1B,
-              "the patch image is copied in 16-byte pieces");
 
 // two fp32 -> one dword of two fp16 (round to nearest even): v_cvt_pk_f16_f32
 __device__ __forceinline__ unsigned pk_e(float a, float b) {
@@ -208,7 +189,7 @@ __device__ __forceinline__ void splitn(const f32x4 &xa, const f32x4 &xb, float s
 #endif
 #ifdef P2P_X3_TIMING                    // phase lengths in s_memtime ticks -> args.raw[0] (tools/x3_timing.py)
 // per-wave counters in LDS (14 more live SGPRs spill): [wave][16] unsigned behind the misc block
-#define XTL_() ((unsigned *)(smb + XSM_MISC + XMISC_FLOATS * 4) + wave * 16)
+#define XTL_() ((unsigned *)(smb + XSM_MISC + 64) + wave * 16)
 #define XT_DECL
 #define XT_START { const unsigned n_ = (unsigned)__builtin_amdgcn_s_memtime(); if (P2P_LANE_ID() < 16) XTL_()[P2P_LANE_ID()] = (P2P_LANE_ID() == 15) ? n_ : 0u; }
 #define XT(i) { const unsigned n_ = (unsigned)__builtin_amdgcn_s_memtime(); if (P2P_LANE_ID() == 0) { unsigned *x_ = XTL_(); x_[i] += n_ - x_[15]; x_[15] = n_; } }
@@ -404,6 +385,80 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
 #pragma unroll 1
     for (int lvl = WINO ? args.lvl0 : 0; lvl < (WINO ? args.lvl0 + 1 : args.nlevels); ++lvl) {
         const RegDev &R_ = args.reg[lvl];
+        // WINO: the gather of proposal i + 1 is issued before the transform + write-out of proposal i (its ~40 scattered loads
+        // per thread land in these registers while that phase runs) and committed to LDS at the top of its own iteration
+        float gn0[2][2], gn1[2][11], gn2[2][4], gn3[2][3];
+        bool pre = false;                    // gn* hold the gather of the proposal the next iteration starts with
+        auto gather_loads = [&](int xa_, int ya_, int xb_, int yb_, const ItemDev &J) {
+            int tv = wave * 64 + P2P_LANE_ID();
+            P2P_OPAQUE(tv);
+#pragma unroll
+            for (int img = 0; img < 2; ++img) {
+                const int Hh = J.H[img], Ww = J.W[img], x0 = img ? xb_ : xa_, y0 = img ? yb_ : ya_;
+                {
+                    const int r0 = clampi(y0, 0, Hh - 1), c0 = clampi(x0, 0, Ww - 1);
+                    const float *src = J.pyr[img][0];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int e = tv + k * NT;
+                        const int c = e >> 8, rem = e & 255, r = rem >> 4, cc = rem & 15;
+                        gn0[img][k] = (e < 768) ? src[((size_t)c * Hh + min(r0 + r, Hh - 1)) * Ww + min(c0 + cc, Ww - 1)] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int j = 1; j < 4; ++j) {
+                    const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
+                    const int Cc = (j == 3) ? 128 : 64;
+                    const int nk = (j == 1) ? 11 : (j == 2) ? 4 : 3;
+                    const int Hj = Hh >> j, Wj = Ww >> j;
+                    const int Ha = level_dim(Hh, j), Wa = level_dim(Ww, j);
+                    const int r0 = clampi(y0 >> j, 0, Hj - 1);
+                    const int c0 = clampi(x0 >> j, 0, Wj - 1);
+                    const float *src = J.pyr[img][j];
+#pragma unroll
+                    for (int k = 0; k < nk; ++k) {
+                        const int e = tv + k * NT;
+                        const int c = e / (Rr * Rr);
+                        const int rem = e - c * (Rr * Rr);
+                        const int r = rem / Rr;
+                        const int cc = rem - r * Rr;
+                        const float v = (e < Cc * Rr * Rr)
+                                            ? src[((size_t)c * Ha + min(r0 + r, Hj - 1)) * Wa + min(c0 + cc, Wj - 1)] : 0.f;
+                        if (j == 1) gn1[img][k] = v; else if (j == 2) gn2[img][k] = v; else gn3[img][k] = v;
+                    }
+                }
+            }
+        };
+        auto gather_commit = [&]() {
+            int tv = wave * 64 + P2P_LANE_ID();
+            P2P_OPAQUE(tv);
+#pragma unroll
+            for (int img = 0; img < 2; ++img) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int e = tv + k * NT;
+                    if (e < 768) raw0[img * 768 + e] = gn0[img][k];
+                }
+                unsigned char *tb = smb + img * XIMG;
+#pragma unroll
+                for (int j = 1; j < 4; ++j) {
+                    const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
+                    const int Cc = (j == 3) ? 128 : 64;
+                    const int nk = (j == 1) ? 11 : (j == 2) ? 4 : 3;
+#pragma unroll
+                    for (int k = 0; k < nk; ++k) {
+                        const int e = tv + k * NT;
+                        if (e < Cc * Rr * Rr) {
+                            const int c = e / (Rr * Rr);
+                            const int rem = e - c * (Rr * Rr);
+                            const float v = (j == 1) ? gn1[img][k] : (j == 2) ? gn2[img][k] : gn3[img][k];
+                            if (j == 1) *(float *)(tb + XOFF1 + (rem / 9) * XRP1 + (rem % 9) * XST1 + c * 4) = v;
+                            else *(float *)(smb + XSHARED + img * XTMPIMG + ((j == 2) ? rem * XTMP2ST : XTMP3 + rem * XTMP3ST) + c * 4) = v;
+                        }
+                    }
+                }
+            }
+        };
 #pragma unroll 1
       for (int cprop = (WINO ? args.p0 : 0) + blockIdx.x; cprop < (WINO ? args.p1 : args.n); cprop += nwg) {
         // WINO: cprop is the compact index of a proposal that exists (its scratch rows), prop its slot; else they coincide
@@ -428,33 +483,20 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
 #endif
             misc[8 + tq] = v;
         }
-        if constexpr (WINO) {                // scales of the prepared patch (patch_prep_kernel): misc[12 + img], misc[20 + img]
-            if (tq >= 8 && tq < 12) {
-                const int q = tq - 8;
-                ((int *)misc)[(q < 2 ? 12 : 18) + q] =
-                    ((const int *)(args.patches + (size_t)(cprop - args.l3c0) * PI_STRIDE + PI_META))[q];
+        if constexpr (WINO) {                // the proposal this work-group takes next (its gather is prefetched): coordinates -> misc[4..7]
+            const int nprop = (cprop + nwg < args.p1) ? wino_slot(args, cprop + nwg) : -1;
+            if (nprop >= 0 && tq >= 4 && tq < 8) {
+                const int q = tq - 4;
+                float v;
+                if (lvl > 0) v = load_coherent(XWS_NEXTP() + (size_t)nprop * 4 + q);
+                else if (args.is_float) v = ((const float *)args.proposals)[(size_t)nprop * 4 + q];
+                else v = (float)((const long long *)args.proposals)[(size_t)nprop * 4 + q];
+                misc[4 + q] = v;
             }
         }
         // per-level reductions behind the power-of-two operand scales: misc[12 + img] = smallest per-pixel L2 scale of the
         // image (float bits, atomic min), misc[14] = largest |H| (float bits, atomic max)
-        if constexpr (WINO) {
-            if (tq == 64) ((int *)misc)[14] = 0;
-        } else {
-            if (tq >= 64 && tq < 67) ((int *)misc)[12 + tq - 64] = (tq < 66) ? 0x7f7fffff : 0;
-        }
-        if constexpr (WINO) {
-            // the prepared patch -> LDS: 88.6 KB in 1 KiB pieces, wave w takes pieces w, w + 8, ... of every range
-            const unsigned char *pg = args.patches + (size_t)(cprop - args.l3c0) * PI_STRIDE;
-            const unsigned l16 = (unsigned)P2P_LANE_ID() * 16u;
-#define XDMA_RANGE(GOFF, LOFF, BYTES)                                                                                   \
-            for (unsigned o_ = (unsigned)wave * 1024u; o_ < (unsigned)(BYTES); o_ += 8u * 1024u)                        \
-                if (o_ + l16 < (unsigned)(BYTES)) P2P_GLOBAL_LOAD_LDS16(pg + (GOFF) + o_ + l16, smb + (LOFF) + o_, 0);
-            XDMA_RANGE(0, 0, PI_IMG)
-            XDMA_RANGE(PI_IMG, XIMG, PI_IMG)
-            XDMA_RANGE(PI_A0, XSHARED, 64 * XA0ST)
-            XDMA_RANGE(PI_TAB, XTAB, PI_TABBYTES)
-            P2P_WAIT_VMCNT(0);
-        }
+        if (tq >= 64 && tq < 67) ((int *)misc)[12 + tq - 64] = (tq < 66) ? 0x7f7fffff : 0;
         __syncthreads();
         // window origins (x, y) in image 1 / image 2 (networks/utils.py:8-19); scalars + selects, never an indexed array
         int moff = 8;                // opaque: the LDS address of misc is otherwise materialised before the loop and spilled
@@ -475,8 +517,10 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
         if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 
         // ------------------------------------------------------------ gather (networks/utils.py:4-36)
-        // (WINO: gather, per-pixel scale, fold table, planes and the level-0 block come prepared: patch_prep_kernel)
-        if constexpr (!WINO) {
+        if constexpr (WINO) {
+            if (!pre) gather_loads(xa, ya, xb, yb, I);       // the work-group's first proposal: nothing was prefetched
+            gather_commit();
+        } else {
             // two passes so that all ~40 scattered 4-byte loads of a thread are in flight together
             float g0[2][2], g1[2][11], g2[2][4], g3[2][3];
 #pragma unroll
@@ -545,6 +589,7 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                     }
                 }
             }
+        }
         if (tidv < 2 * XNPL * (3 * YST2 + 2 * YST3) / 16) {  // the zero areas: the dead rows of the cell tiles multiply zeros
             const int per = (3 * YST2 + 2 * YST3) / 16;
             const int im = tidv / (XNPL * per), pl = (tidv / per) % XNPL, q = tidv % per;
@@ -570,7 +615,6 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                 for (int c = 0; c < 3; ++c) ss = fmaf(p[c * 256], p[c * 256], ss);
             }
             const int c2 = patch_cell(XY0(img), py, 2, I.H[img]) * 5 + patch_cell(XX0(img), px, 2, I.W[img]);
-            const int c3 = patch_cell(XY0(img), py, 3, I.H[img]) * 3 + patch_cell(XX0(img), px, 3, I.W[img]);
 #pragma unroll
             for (int j = 1; j < 4; ++j) {
                 const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
@@ -590,7 +634,7 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
             scale[tidv] = sc * 4096.0f;
             atomicMin((int *)misc + 12 + img, __float_as_int(sc));
             sc_keep = sc;
-            c23_keep = c2 * XTROW | c3 * XTROW << 16;
+            c23_keep = c2 * XTROW | (patch_cell(XY0(img), py, 3, I.H[img]) * 3 + patch_cell(XX0(img), px, 3, I.W[img])) * XTROW << 16;
             if (tidv < 2 * 33) {     // ring = the zero padding of conv1: scale 0
                 const int im = tidv / 33, q = tidv - im * 33;
                 const int idx = (q < 17) ? q : (q - 16) * 17;
@@ -638,7 +682,6 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
             *(float *)(smb + XSHARED + m * XA0ST + kk * 4) = v;
         }
         __syncthreads();
-        }
         XT(2)
 
         // ------------------------------------------------------------ conv1: 3x3, stride 2, pad 1
@@ -650,8 +693,7 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
         const f32x16 zero16 = {0};
         {
             f32x4 R0[2], R1[2];
-            const unsigned char *wb = WINO ? (const unsigned char *)R_.wh1w + (size_t)wave * (S1W_UNITS + XPF) * XUB
-                                           : (const unsigned char *)R_.wh1 + (size_t)wave * (S1_UNITS + XPF) * XUB;
+            const unsigned char *wb = (const unsigned char *)R_.wh1 + (size_t)wave * (S1_UNITS + XPF) * XUB;
             const unsigned wlane = (tidv & 63) * 16;
             XLOADB(B0, 0) XLOADB(B1, 1) XLOADB(B2, 2) XLOADB(B3, 3) XLOADB(B4, 4) XLOADB(B5, 5)
             {   // level 0 of both images: 4 slabs of the pre-scaled block
@@ -672,30 +714,6 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
             float *Tw = (float *)(smb + XSHARED + (wave & (XT2N - 1)) * XTW) + l31;
             float *T3w = (float *)(smb + XSHARED + XT2N * XTW + wave * (9 * XTROW));
             const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
-            // WINO: the level-3 partial sums T3[step][this wave's 64 channels][9 cells] of the proposal were computed by
-            // l3_gemm_kernel (regress_l3.hip); 2304 contiguous bytes per (step, wave), copied by LDS-DMA straight into this wave's
-            // fold buffer one step ahead: step 0 here, step s + 1 right behind the fold of step s (the wave is the buffer's only
-            // reader).  Between that issue and the fold that reads the rows this wave issues >= 16 weight loads and consumes
-            // them; loads return in order, so XT3_WAIT's counted wait (never reached in practice) is what makes it formal.
-#ifdef XF_T3_SAME                       // timing experiment (wrong results): every proposal reads the (cache-resident) rows of the first
-#define XT3_PROP() 0
-#else
-#define XT3_PROP() (cprop - args.l3c0)
-#endif
-#ifdef XF_T3_NODMA                      // timing experiment (wrong results): the level-3 rows are never fetched
-#define XT3_ISSUE(step_)
-#else
-#define XT3_ISSUE(step_)                                                                                              \
-            if constexpr (WINO) {                                                                                     \
-                P2P_WAVE_SYNC();         /* every lane's reads of the previous rows are done */                         \
-                const unsigned char *g3_ = (const unsigned char *)args.l3T +                                          \
-                    ((size_t)XT3_PROP() * (18 * 8) + (unsigned)((step_) * 8 + wave)) * (9 * XTROW) + (unsigned)P2P_LANE_ID() * 16u; \
-                P2P_GLOBAL_LOAD_LDS16(g3_, (unsigned char *)T3w, 0); P2P_GLOBAL_LOAD_LDS16(g3_, (unsigned char *)T3w, 1024);   \
-                if (P2P_LANE_ID() < 16) P2P_GLOBAL_LOAD_LDS16(g3_, (unsigned char *)T3w, 2048);                        \
-            }
-#endif
-#define XT3_WAIT() if constexpr (WINO) { P2P_WAIT_VMCNT(16); }
-            XT3_ISSUE(0)
             // The K-ranges (tap, image) are walked in 18 steps.  A step = the pixel slabs of level 1 (P), the cell slabs
             // of levels 2 + 3 (C) and the fold (F).  Waves 0-3 run P(i) C(i) F(i); waves 4-7 -- each shares its SIMD with
             // one of waves 0-3 -- run C(i) F(i) P(i) (their weight stream is packed in that order), so that a fold, which
@@ -759,17 +777,9 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                     f32x16 t0, t1;
                     XPB_C0(grp)
 #if defined(XF_SKIP_C)
-                    t0 = acc00; t1 = acc01; XWADV(WINO ? 8 : 24) (void)q2; (void)q3;
+                    t0 = acc00; t1 = acc01; XWADV(24) (void)q2; (void)q3;
 #else
-                    if constexpr (WINO) {
-                        (void)q3; (void)zero4;
-                        // level 2 only: 4 slabs of 16 channels, rows = level-2 cells (level 3: T3 rows from regress_l3.hip)
-                        XLOADP(S0, q2, YPL2)
-                        XGROUP4(XCSLAB(XHALFZ, S0, S1, q2 + 32, YPL2, B0, B1, B6, B7, 6),
-                                XCSLAB(XHALF, S1, S0, q2 + 64, YPL2, B2, B3, B0, B1, 8),
-                                XCSLAB(XHALF, S0, S1, q2 + 96, YPL2, B4, B5, B2, B3, 10),
-                                XCSLAB(XHALF, S1, S0, q2 + 96, YPL2, B6, B7, B4, B5, 12))
-                    } else {
+                    {
                         (void)q3;
                         // level 3 first: 4 K steps of 32 channels x 4 n-tiles of 16 columns, rows = the 9 cells
                         const int l16 = (tidv & 15), kb = (tidv >> 4) & 3;
@@ -815,18 +825,7 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                         }
                     }
                     P2P_WAVE_SYNC();
-                    XT3_WAIT()
                     {
-                        // WINO: T3 carries the exponent of l3_prep_kernel (cells x 2^(138 - eb3)), the table entry that of the image's
-                        // level-2 planes (scale[pixel] x 2^(127 - eb)): T3 x 2^(eb3 + eb - 253) brings it to the table's scale
-                        float r3 = 1.0f;
-                        if constexpr (WINO) {
-                            int mo3 = 12;
-                            P2P_OPAQUE(mo3);
-                            const int eb = clampi((((const int *)misc)[mo3 + img] >> 23) & 0xff, 13, 240);
-                            const int eb3 = ((const int *)misc)[mo3 + 8 + img];
-                            r3 = __int_as_float(clampi(eb3 + eb - 126, 1, 254) << 23);
-                        }
                         const unsigned char *tabp = smb + XTAB + img * XTABIMG + (ky * 17 + kx + 8 * half) * 8;
                         const unsigned char *Tr = (const unsigned char *)Tw;
 #pragma unroll
@@ -837,8 +836,7 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                                 const int offs = __float_as_int(e[1]);
                                 const float *g = (const float *)(Tr + (offs & 0xffff));
                                 const float *h3 = (const float *)((const unsigned char *)(T3w + l31) + (offs >> 16));
-                                const float v0 = WINO ? fmaf(h3[0], r3, g[0]) : g[0] + h3[0];
-                                const float v1 = WINO ? fmaf(h3[32], r3, g[32]) : g[32] + h3[32];
+                                const float v0 = g[0] + h3[0], v1 = g[32] + h3[32];
                                 if (t == 0) { acc00[r] = fmaf(e[0], v0, acc00[r]); acc01[r] = fmaf(e[0], v1, acc01[r]); }
                                 else        { acc10[r] = fmaf(e[0], v0, acc10[r]); acc11[r] = fmaf(e[0], v1, acc11[r]); }
                                 if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // four rows in flight, not all 32
@@ -847,7 +845,6 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
 #else
                     acc00 += t0; acc01 += t1;
 #endif
-                    if (it + 1 < 18) { XT3_ISSUE(it + 1) }
                     XPB_F(stagger, grp)
                     XTL(6)
                 }
@@ -903,6 +900,33 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
             }
             __syncthreads();
             XT(8)
+            // the next proposal's gather: in flight during the transform and the write-out below (its slot is looked up again:
+            // one value less alive across conv1)
+            const int nprop2 = (cprop + nwg < args.p1) ? wino_slot(args, cprop + nwg) : -1;
+            pre = nprop2 >= 0;
+            if (pre) {
+                int nit = 0;
+                while (nit + 1 < args.nitems && nprop2 >= args.start[nit + 1]) ++nit;
+                int mo2 = 4;
+                P2P_OPAQUE(mo2);
+                gather_loads((int)misc[mo2 + 0] - 8, (int)misc[mo2 + 1] - 8, (int)misc[mo2 + 2] - 8, (int)misc[mo2 + 3] - 8, args.item[nit]);
+            } else {
+                // (defined on this path too: otherwise the values committed at the top of this iteration count as live across
+                // conv1 -- the compiler does not see that `pre == false` makes the next iteration reload them -- 40 registers)
+                float zf = 0.f;
+                P2P_OPAQUE(zf);
+#pragma unroll
+                for (int im = 0; im < 2; ++im) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) gn0[im][k] = zf;
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) gn1[im][k] = zf;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) gn2[im][k] = zf;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) gn3[im][k] = zf;
+                }
+            }
             // item = K chunk of 32 channels: lane = (tile, 8 channels), two passes of 4 channels; a lane's 8 values of a
             // (position, plane) are ONE 16-byte store and a wave's store covers the proposal's 16 rows of a block = 1 KiB
             // contiguous (8-byte stores in 64-byte runs cost 2 ms of a 14.5 ms launch in write bandwidth)
@@ -1147,259 +1171,6 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
 }
 
 // --------------------------------------------------------------------------------------------------
-// patch_prep_kernel (P2P_REGRESS_FP16X2W): one work-group of 256 threads per (proposal, image), three of them per compute unit.
-// Everything a proposal needs before its first MFMA, for ALL proposals of a round at once (the persistent conv1 kernel ran these
-// latency-bound phases one proposal at a time per compute unit: 2.4 of its 8 ms):
-//   gather of the four pyramid levels (networks/utils.py:4-36, same clamps), per-pixel L2 scale (patch2pix.py:173-174), the
-//   image's power-of-two scale (header of this file), the fold table, level 2 as two fp16 planes, this image's half of the
-//   pre-scaled level-0 im2col block -> the patch image (PI_* above), copied into LDS by regress_h2_kernel<true>;
-//   level 3 (3 x 3 cells x 128 channels) x 2^(138 - eb3) as two fp16 planes -> the A rows of l3_gemm_kernel (regress_l3.hip).
-struct PatchPrepArgs {
-    unsigned char *patches;      // [cn][PI_STRIDE]
-    unsigned char *A3;           // [img 2][rowblocks][K chunk 4][WINO_BLK]
-    int c0, cn, rowblocks, lvl;
-};
-constexpr int PNT = 256;
-constexpr int PP_L1 = 0;                              // level 1 fp32: the grid layout of the conv1 kernel (XRP1 / XST1)
-constexpr int PP_TMP = PP_L1 + 9 * XRP1;              // fp32 copy of levels 2 / 3 (XTMP2ST / XTMP3 / XTMP3ST)
-constexpr int PP_PL2 = PP_TMP + XTMPIMG;              // level 2 as planes (YST2 / YPL2, with their zero areas)
-constexpr int PP_RAW = PP_PL2 + XNPL * YPL2;          // level 0 raw [3][256]
-constexpr int PP_SCL = PP_RAW + 3 * 256 * 4;          // scale [256]
-constexpr int PP_TAB = PP_SCL + 256 * 4;              // fold table [17][17] x 8 B
-constexpr int PP_MISC = PP_TAB + XTABIMG + 8;         // [0] smallest scale (float bits), [1] eb3, [2..10] level-3 sums of squares
-constexpr int PP_BYTES = PP_MISC + 64;
-static_assert(PP_TMP % 16 == 0 && PP_PL2 % 16 == 0 && PP_RAW % 16 == 0 && PP_SCL % 16 == 0 && PP_TAB % 16 == 0 && PP_MISC % 16 == 0 &&
-              PP_BYTES <= 52 * 1024, "three work-groups per compute unit");
-
-__global__ __launch_bounds__(PNT) void patch_prep_kernel(RegressArgs args, PatchPrepArgs x) {
-    __shared__ __attribute__((aligned(16))) unsigned char ps[PP_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, img = blockIdx.y, cl = blockIdx.x;
-    const int slot = (cl < x.cn) ? wino_slot(args, x.c0 + cl) : -1;
-    // the 16-byte pieces of this block's 9 level-3 rows in the GEMM's A blocks: item = (cell, piece of 8 channels), 144 of them
-    auto piece_ptr = [&](int it) {
-        const int cell = it >> 4, piece = it & 15;
-        const unsigned R = (unsigned)cl * 9u + (unsigned)cell, rb = R >> 7, r = R & 127u;
-        const unsigned kc = (unsigned)piece >> 2, q = (unsigned)piece & 3u;
-        return (rb < (unsigned)x.rowblocks)
-                   ? x.A3 + ((size_t)((unsigned)img * (unsigned)x.rowblocks + rb) * 4 + kc) * WINO_BLK + (r * 4u + (q ^ ((r >> 2) & 3u))) * 16u
-                   : (unsigned char *)nullptr;
-    };
-    if (slot < 0) {      // no such proposal: its GEMM rows (inside the allocated row blocks) are zeros, never uninitialised memory
-        if (tid < 144) {
-            unsigned char *d = piece_ptr(tid);
-            if (d) {
-                *(uint4 *)d = make_uint4(0u, 0u, 0u, 0u);
-                *(uint4 *)(d + WINO_BLK / 2) = make_uint4(0u, 0u, 0u, 0u);
-            }
-        }
-        return;
-    }
-    int it = 0;
-    while (it + 1 < args.nitems && slot >= args.start[it + 1]) ++it;
-    const ItemDev &I = args.item[it];
-    // the window origin in this image (networks/utils.py:8-19: x, y = imatches.long(), window [-8, 7])
-    float vx, vy;
-    if (x.lvl > 0) {
-        const float *np = args.ws + ((2 * (size_t)args.n * 512 + 31) & ~(size_t)31) + (size_t)slot * 4 + 2 * img;
-        vx = np[0]; vy = np[1];
-    } else if (args.is_float) {
-        const float *pp = (const float *)args.proposals + (size_t)slot * 4 + 2 * img;
-        vx = pp[0]; vy = pp[1];
-    } else {
-        const long long *pp = (const long long *)args.proposals + (size_t)slot * 4 + 2 * img;
-        vx = (float)pp[0]; vy = (float)pp[1];
-    }
-    const int x0 = (int)vx - 8, y0 = (int)vy - 8;
-    const int Hh = I.H[img], Ww = I.W[img];
-    float *raw0 = (float *)(ps + PP_RAW), *scale = (float *)(ps + PP_SCL), *pmisc = (float *)(ps + PP_MISC);
-
-    // ------------------------------------------------------------ gather: every load of a thread in flight together
-    float g0[3], g1[21], g2[7], g3[2][9];
-    {
-        const int r0 = clampi(y0, 0, Hh - 1), c0 = clampi(x0, 0, Ww - 1);
-        const float *src = I.pyr[img][0];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int e = tid + k * PNT;
-            const int c = e >> 8, rem = e & 255, r = rem >> 4, cc = rem & 15;
-            g0[k] = src[((size_t)c * Hh + min(r0 + r, Hh - 1)) * Ww + min(c0 + cc, Ww - 1)];
-        }
-    }
-#pragma unroll
-    for (int j = 1; j < 3; ++j) {
-        const int Rr = (j == 1) ? 9 : 5, nk = (j == 1) ? 21 : 7;
-        const int Hj = Hh >> j, Wj = Ww >> j;                     // index clamp: dim // ds (networks/utils.py:22-23)
-        const int Ha = level_dim(Hh, j), Wa = level_dim(Ww, j);  // extent of the backbone's map
-        const int r0 = clampi(y0 >> j, 0, Hj - 1), c0 = clampi(x0 >> j, 0, Wj - 1);
-        const float *src = I.pyr[img][j];
-#pragma unroll
-        for (int k = 0; k < nk; ++k) {
-            const int e = tid + k * PNT;
-            const int c = e / (Rr * Rr);
-            const int rem = e - c * (Rr * Rr);
-            const int r = rem / Rr;
-            const int cc = rem - r * Rr;
-            const float v = (e < 64 * Rr * Rr) ? src[((size_t)c * Ha + min(r0 + r, Hj - 1)) * Wa + min(c0 + cc, Wj - 1)] : 0.f;
-            if (j == 1) g1[k] = v; else g2[k] = v;
-        }
-    }
-    if (wave == 0) {     // level 3: one wave, channels lane and lane + 64 of the 3 x 3 cells
-        const int Hj = Hh >> 3, Wj = Ww >> 3, Ha = level_dim(Hh, 3), Wa = level_dim(Ww, 3);
-        const int r0 = clampi(y0 >> 3, 0, Hj - 1), c0 = clampi(x0 >> 3, 0, Wj - 1);
-        const float *src = I.pyr[img][3];
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int cell = 0; cell < 9; ++cell)
-                g3[k][cell] = src[((size_t)(lane + 64 * k) * Ha + min(r0 + cell / 3, Hj - 1)) * Wa + min(c0 + cell % 3, Wj - 1)];
-    }
-    // zeros: the pads of the level-1 grid, the zero areas of the level-2 planes, the padding ring of the fold table
-    for (int q = tid; q < (9 * XRP1) / 16; q += PNT) *(f32x4 *)(ps + PP_L1 + q * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (tid < XNPL * (3 * YST2 / 16)) {
-        const int pl = tid / (3 * YST2 / 16), q = tid - pl * (3 * YST2 / 16);
-        *(f32x4 *)(ps + PP_PL2 + pl * YPL2 + YNC2 * YST2 + q * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    if (tid < 33) {
-        const int idx = (tid < 17) ? tid : (tid - 16) * 17;
-        *(f32x2 *)(ps + PP_TAB + idx * 8) = (f32x2){0.f, 0.f};
-    }
-    if (tid == 0) ((int *)pmisc)[0] = 0x7f7fffff;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 3; ++k) raw0[tid + k * PNT] = g0[k];
-#pragma unroll
-    for (int k = 0; k < 21; ++k) {
-        const int e = tid + k * PNT;
-        if (e < 64 * 81) {
-            const int c = e / 81, rem = e - c * 81;
-            *(float *)(ps + PP_L1 + (rem / 9) * XRP1 + (rem % 9) * XST1 + c * 4) = g1[k];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        const int e = tid + k * PNT;
-        if (e < 64 * 25) {
-            const int c = e / 25, rem = e - c * 25;
-            *(float *)(ps + PP_TMP + rem * XTMP2ST + c * 4) = g2[k];
-        }
-    }
-    if (wave == 0) {
-        float mx = 0.f, ss[9];
-#pragma unroll
-        for (int cell = 0; cell < 9; ++cell) {
-            *(float *)(ps + PP_TMP + XTMP3 + cell * XTMP3ST + lane * 4) = g3[0][cell];
-            *(float *)(ps + PP_TMP + XTMP3 + cell * XTMP3ST + (lane + 64) * 4) = g3[1][cell];
-            ss[cell] = fmaf(g3[1][cell], g3[1][cell], g3[0][cell] * g3[0][cell]);
-            mx = fmaxf(mx, fmaxf(fabsf(g3[0][cell]), fabsf(g3[1][cell])));
-        }
-        // a fixed butterfly: the same sums whatever the launch
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-#pragma unroll
-            for (int cell = 0; cell < 9; ++cell) ss[cell] += __shfl_xor(ss[cell], m);
-            mx = fmaxf(mx, __shfl_xor(mx, m));
-        }
-#pragma unroll
-        for (int cell = 0; cell < 9; ++cell)
-            if (lane == cell) pmisc[2 + cell] = ss[cell];
-        if (lane == 9) ((int *)pmisc)[1] = clampi((__float_as_int(mx) >> 23) & 0xff, 20, 250);
-    }
-    __syncthreads();
-
-    // ------------------------------------------------------------ per-pixel L2 scale (patch2pix.py:173-174): thread = pixel
-    const int py = tid >> 4, px = tid & 15;
-    float sc;
-    int c23;
-    {
-        float ss = 0.f;
-        {
-            const float *p = raw0 + patch_cell(y0, py, 0, Hh) * 16 + patch_cell(x0, px, 0, Ww);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) ss = fmaf(p[c * 256], p[c * 256], ss);
-        }
-        const int c2 = patch_cell(y0, py, 2, Hh) * 5 + patch_cell(x0, px, 2, Ww);
-        const int c3 = patch_cell(y0, py, 3, Hh) * 3 + patch_cell(x0, px, 3, Ww);
-#pragma unroll
-        for (int j = 1; j < 3; ++j) {
-            const int cjy = patch_cell(y0, py, j, Hh), cjx = patch_cell(x0, px, j, Ww);
-            const unsigned char *p = (j == 1) ? ps + PP_L1 + cjy * XRP1 + cjx * XST1 : ps + PP_TMP + (cjy * 5 + cjx) * XTMP2ST;
-            for (int c = 0; c < 64; c += 4) {
-                const f32x4 v = *(const f32x4 *)(p + c * 4);
-                ss = fmaf(v[0], v[0], ss); ss = fmaf(v[1], v[1], ss); ss = fmaf(v[2], v[2], ss); ss = fmaf(v[3], v[3], ss);
-            }
-        }
-        ss += pmisc[2 + c3];
-        sc = 1.0f / sqrtf(ss + 1e-6f);
-        scale[tid] = sc * 4096.0f;
-        atomicMin((int *)pmisc, __float_as_int(sc));
-        c23 = c2 * XTROW | c3 * XTROW << 16;
-    }
-    __syncthreads();
-    const int eb = clampi((((const int *)pmisc)[0] >> 23) & 0xff, 13, 240);
-    *(f32x2 *)(ps + PP_TAB + ((py + 1) * 17 + px + 1) * 8) = (f32x2){sc * __int_as_float((254 - eb) << 23), __int_as_float(c23)};
-    {   // level 2 as planes: every component times 2^(eb + 12 - 127) is <= 2^12
-        const float mul = __int_as_float((eb + 12) << 23);
-        for (int e = tid; e < 1600; e += PNT) {
-            const int cell = e >> 6, c = e & 63;
-            store_planes(ps + PP_PL2 + cell * YST2 + c * 2, YPL2, *(const float *)(ps + PP_TMP + cell * XTMP2ST + c * 4) * mul);
-        }
-    }
-    unsigned char *pg = x.patches + (size_t)cl * PI_STRIDE;
-    // this image's half of the level-0 im2col block, pre-scaled: A0[64 px][K = img * 32 + tap * 3 + c]
-    for (int e = tid; e < 64 * 32; e += PNT) {
-        const int m = e >> 5, r = e & 31;
-        float v = 0.f;
-        if (r < 27) {
-            const int tap = r / 3, c = r - tap * 3, ky = tap / 3, kx = tap - ky * 3;
-            const int qy = 2 * (m >> 3) + ky - 1, qx = 2 * (m & 7) + kx - 1;
-            if (qy >= 0 && qx >= 0)
-                v = raw0[c * 256 + patch_cell(y0, qy, 0, Hh) * 16 + patch_cell(x0, qx, 0, Ww)] * scale[qy * 16 + qx];
-        }
-        *(float *)(pg + PI_A0 + m * XA0ST + (img * 32 + r) * 4) = v;
-    }
-    if (img == 0 && tid < 64) *(f32x4 *)(pg + PI_A0 + tid * XA0ST + 64 * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};      // the row pads
-    __syncthreads();
-    // LDS -> the patch image: level-1 grid + level-2 planes, the fold table, the scales, the two exponents
-    for (int q = tid; q < PI_IMG / 16; q += PNT) {
-        const int o = q * 16;
-        *(f32x4 *)(pg + img * PI_IMG + o) = *(const f32x4 *)(ps + (o < YOFF2 ? PP_L1 + o : PP_PL2 + (o - YOFF2)));
-    }
-    for (int q = tid; q < XTABIMG / 8; q += PNT) *(f32x2 *)(pg + PI_TAB + img * XTABIMG + q * 8) = *(const f32x2 *)(ps + PP_TAB + q * 8);
-    if (img == 0 && tid < 4) *(float *)(pg + PI_TAB + 2 * XTABIMG + tid * 4) = 0.f;
-    scale = (float *)(ps + PP_SCL);
-    *(float *)(pg + PI_TAB + 2 * XTABIMG + 16 + (img * 256 + tid) * 4) = scale[tid];
-    if (tid < 2) ((int *)(pg + PI_META))[tid * 2 + img] = ((const int *)pmisc)[tid];
-    // level 3 -> the GEMM rows
-    if (tid < 144) {
-        const float mul = __int_as_float((265 - ((const int *)pmisc)[1]) << 23);          // largest magnitude -> [2^11, 2^12)
-        unsigned char *d = piece_ptr(tid);
-        const float *p = (const float *)(ps + PP_TMP + XTMP3 + (tid >> 4) * XTMP3ST) + (tid & 15) * 8;
-        const f32x4 a = *(const f32x4 *)p, b = *(const f32x4 *)(p + 4);
-        const float w[8] = {a[0] * mul, a[1] * mul, a[2] * mul, a[3] * mul, b[0] * mul, b[1] * mul, b[2] * mul, b[3] * mul};
-        unsigned h0[4], h1[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            h0[q] = pk_e(w[2 * q], w[2 * q + 1]);
-            h1[q] = pk_e(w[2 * q] - pk_lo(h0[q]), w[2 * q + 1] - pk_hi(h0[q]));
-        }
-        if (d) {
-            *(uint4 *)d = make_uint4(h0[0], h0[1], h0[2], h0[3]);
-            *(uint4 *)(d + WINO_BLK / 2) = make_uint4(h1[0], h1[1], h1[2], h1[3]);
-        }
-    }
-}
-
-int launch_patch_prep(const RegressArgs &a, int c0, int c1, unsigned char *patches, unsigned char *A3, hipStream_t stream) {
-    const int cn = c1 - c0;
-    if (cn <= 0) return P2P_OK;
-    PatchPrepArgs x;
-    x.patches = patches; x.A3 = A3; x.c0 = c0; x.cn = cn; x.rowblocks = (9 * cn + 127) / 128; x.lvl = a.lvl0;
-    // every row of the GEMM's allocated row blocks is written: the tail of the last block (proposals beyond cn) as zeros
-    hipLaunchKernelGGL(patch_prep_kernel, dim3((x.rowblocks * 128 + 8) / 9, 2), dim3(PNT), 0, stream, a, x);
-    return check_launch("patch_prep_kernel");
-}
-
-// --------------------------------------------------------------------------------------------------
 // host side: the weight streams.  conv1: units 0-7 = level 0 ([4 slabs][n-tile]), then [tap][img][16 slabs][n-tile]
 // (waves 4-7: the 12 cell slabs of a step before its 4 pixel slabs);
 // conv2: [chunk of 128 input channels][tap][8 slabs][n-tile].  A unit is [plane 2][lane 64][8 fp16]; K of a conv1
@@ -1450,8 +1221,6 @@ static void channel_exponents(const float *w, int rows, int per_row, int *t) {
         }
     }
 }
-
-void conv1_channel_exponents(const float *conv1_w, int *t1) { channel_exponents(conv1_w, 512, 518 * 9, t1); }
 
 void pack_h2_weights(const float *conv1_w, const float *conv2_w, float *wx1, float *wx2, int *t1, int *t2) {
     uint16_t *d1 = (uint16_t *)wx1, *d2 = (uint16_t *)wx2;
@@ -1513,33 +1282,6 @@ void pack_h2_weights(const float *conv1_w, const float *conv2_w, float *wx1, flo
                         const int n = 64 * w + 32 * u + (lane & 31);
                         const int ch = chunk * 128 + sin * 16 + 8 * (lane >> 5) + j;
                         putn(d2, base, lane, j, W2(n, ch, tap));
-                    }
-            }
-        }
-}
-
-// FP16X2W: conv1's stream without level 3 (regress_l3.hip multiplies it for all proposals at once): per wave 4 slabs of level
-// 0, then per (tap, image) step 4 slabs of level 1 and 4 of level 2 -- waves 0-3 in that order, waves 4-7 level 2 first.
-// Unit layout and the K of a slab as in pack_h2_weights / split_conv1_index; t1 = that function's channel exponents.
-void pack_h2w_conv1(const float *conv1_w, const int *t1, float *wx) {
-    uint16_t *d = (uint16_t *)wx;
-    auto W1 = [&](int n, int ch, int tap) { return std::ldexp(conv1_w[((size_t)n * 518 + ch) * 9 + tap], t1[n]); };
-    for (int w = 0; w < 8; ++w)
-        for (int pos = 0; pos < S1W_SLABS; ++pos) {
-            int slab = pos;                  // canonical numbering of split_conv1_index: per step 0-3 level 1, 4-7 level 2
-            if (pos >= 4) {
-                const int step = (pos - 4) / 8, j = (pos - 4) % 8;
-                const int canon = (w >= 4) ? ((j < 4) ? 4 + j : j - 4) : j;
-                slab = 4 + step * 16 + canon;
-            }
-            for (int u = 0; u < 2; ++u) {
-                const size_t base = ((size_t)w * (S1W_UNITS + XPF) + pos * 2 + u) * (XNPL * 64);
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 8; ++j) {
-                        const int n = 64 * w + 32 * u + (lane & 31);
-                        int ch, tap;
-                        split_conv1_index(slab, lane >> 5, j, ch, tap);
-                        putn(d, base, lane, j, (ch < 0) ? 0.f : W1(n, ch, tap));
                     }
             }
         }

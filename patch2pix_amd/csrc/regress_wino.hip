@@ -267,38 +267,23 @@ int launch_regress_wino(RegressArgs a, int n, hipStream_t stream) {
     P2P_REQUIRE(a.ws, P2P_EINVAL, "%s: the scratch buffer is missing", "launch_regress_wino");
     unsigned char *wsU = (unsigned char *)(a.ws + wino_u_offset_floats((size_t)n));
     float *hinv = a.ws + wino_hinv_offset_floats((size_t)n);
-    float *T3 = a.ws + l3_t_offset_floats((size_t)n);
-    unsigned char *A3 = (unsigned char *)(a.ws + l3_a_offset_floats((size_t)n));
-    unsigned char *patches = (unsigned char *)(a.ws + pi_offset_floats((size_t)n));
     for (int lvl = 0; lvl < a.nlevels; ++lvl) {
-        a.lvl0 = lvl;
-        // rounds of at most L3_CHUNK proposals: the patches of the whole round (patch_prep_kernel) and level 3 of conv1 (18 GEMMs -> T3),
-        // then chunk by chunk conv1 -> transformed conv2 input (regress_h2_kernel<true>) and the Winograd GEMMs (-> V)
-        for (int l0 = 0; l0 < n; l0 += L3_CHUNK) {
-            const int l1 = std::min(n, l0 + L3_CHUNK);
-            int st = launch_patch_prep(a, l0, l1, patches, A3, stream);
+        for (int ch = 0, nch = wino_nchunks((size_t)n); ch < nch; ++ch) {
+            int p0, p1;
+            wino_chunk_range((size_t)n, ch, &p0, &p1);
+            const int cn = p1 - p0, mblocks = (cn + 7) / 8;
+            if (cn <= 0) continue;
+            a.lvl0 = lvl; a.p0 = p0; a.p1 = p0 + cn; a.wU = wsU; a.hinv = hinv; a.mblocks = mblocks;
+            int st = launch_regress_h2_conv1(a, cn, stream);
             if (st != P2P_OK) return st;
-            st = launch_regress_l3(a, l0, l1, A3, T3, stream);
+            WinoArgs w;
+            w.U = wsU; w.Wt = (const unsigned char *)a.reg[lvl].ww2; w.bn2s = a.reg[lvl].bn2s_w; w.bn2b = a.reg[lvl].bn2b;
+            w.hinv = hinv; w.V = a.ws + (size_t)lvl * n * 512; w.mblocks = mblocks; w.p0 = p0; w.n = n;
+            w.dev_counts = a.dev_counts; w.nitems = a.nitems;
+            for (int b = 0; b <= MAXB; ++b) w.start[b] = a.start[b];
+            hipLaunchKernelGGL(wino_gemm_kernel, dim3(((mblocks + 7) / 8) * 32), dim3(WNT), WLDS, stream, w);
+            st = check_launch("wino_gemm_kernel");
             if (st != P2P_OK) return st;
-            a.patches = patches; a.l3T = T3; a.l3c0 = l0;
-            for (int ch = 0, nch = wino_nchunks((size_t)(l1 - l0)); ch < nch; ++ch) {
-                int p0, p1;
-                wino_chunk_range((size_t)(l1 - l0), ch, &p0, &p1);
-                p0 += l0; p1 += l0;
-                const int cn = p1 - p0, mblocks = (cn + 7) / 8;
-                if (cn <= 0) continue;
-                a.p0 = p0; a.p1 = p1; a.wU = wsU; a.hinv = hinv; a.mblocks = mblocks;
-                st = launch_regress_h2_conv1(a, cn, stream);
-                if (st != P2P_OK) return st;
-                WinoArgs w;
-                w.U = wsU; w.Wt = (const unsigned char *)a.reg[lvl].ww2; w.bn2s = a.reg[lvl].bn2s_w; w.bn2b = a.reg[lvl].bn2b;
-                w.hinv = hinv; w.V = a.ws + (size_t)lvl * n * 512; w.mblocks = mblocks; w.p0 = p0; w.n = n;
-                w.dev_counts = a.dev_counts; w.nitems = a.nitems;
-                for (int b = 0; b <= MAXB; ++b) w.start[b] = a.start[b];
-                hipLaunchKernelGGL(wino_gemm_kernel, dim3(((mblocks + 7) / 8) * 32), dim3(WNT), WLDS, stream, w);
-                st = check_launch("wino_gemm_kernel");
-                if (st != P2P_OK) return st;
-            }
         }
         hipLaunchKernelGGL(regress_fc_kernel, dim3(std::min(n, ncu)), dim3(NT), FC_LDS_BYTES, stream, a, lvl);
         const int st = check_launch("regress_fc_kernel");

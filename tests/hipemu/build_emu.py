@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "patch2pix_amd", "csrc")
 OUT = os.path.join(HERE, "_build", "libp2p_emu.so")
-SOURCES = ["api.hip", "backbone.hip", "coarse.hip", "consensus.hip", "filter.hip", "regress.hip", "regress_h2.hip", "regress_wino.hip", "regress_l3.hip"]
+SOURCES = ["api.hip", "backbone.hip", "coarse.hip", "consensus.hip", "filter.hip", "regress.hip", "regress_h2.hip", "regress_wino.hip"]
 
 
 def build(force=False, verbose=False):

@@ -8,7 +8,7 @@
 set -eu
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$ROOT/tools/exp"
-FILES=${FILES:-"api regress regress_h2 regress_wino regress_l3"}
+FILES=${FILES:-"api regress regress_h2 regress_wino"}
 if [ "${1:-}" = "--run" ]; then
     mode=$2; shift 2
     for name in "$@"; do
@@ -23,7 +23,7 @@ for spec in "$@"; do
     [ "$spec" != "$name" ] && flags="-DP2P_EXPERIMENT $(echo "${spec#*=}" | tr ',' ' ')"
     tmp=$(mktemp -d)
     objs=""
-    for f in api backbone coarse consensus filter regress regress_h2 regress_wino regress_l3; do
+    for f in api backbone coarse consensus filter regress regress_h2 regress_wino; do
         if [ -n "$flags" ] && echo " $FILES " | grep -q " $f "; then
             /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c "$ROOT/patch2pix_amd/csrc/$f.hip" -o "$tmp/$f.o" -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "Function Name|VGPRs:|AGPRs:|ScratchSize|error" | grep -B3 -A0 "ScratchSize \[bytes/lane\]: [1-9]\|error" || true
             objs="$objs $tmp/$f.o"
