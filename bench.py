@@ -49,6 +49,10 @@ CONFIGS = {
 # algorithmic work of one regress launch: per proposal per level
 #   conv1 2*64*512*(518*9) + conv2 2*64*512*(512*9) + fc 2*(512*512+512*256+256*5) flop
 FLOP_PER_PROPOSAL_LEVEL = 2 * 64 * 512 * (518 * 9) + 2 * 64 * 512 * (512 * 9) + 2 * (512 * 512 + 512 * 256 + 256 * 5)
+# fp16 MFMA flop the default mode ISSUES per proposal and level (regress_h2.hip / regress_wino.hip): conv1 after the cell-row
+# de-duplication = per wave 48 + 18 x 72 v_mfma_f32_32x32x16_f16 (32 768 flop) and 18 x 96 v_mfma_f32_16x16x32_f16 (16 384 flop),
+# 8 waves; conv2 as Winograd = 16 positions x 16 tile rows x 512 x 512 x 2 flop x 3 products; the FC tail runs on fp32 MFMA
+ISSUED_FP16_FLOP_PER_PROPOSAL_LEVEL = 8 * ((48 + 18 * 72) * 32768 + 18 * 96 * 16384) + 16 * 16 * 512 * 512 * 2 * 3
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 MODES = {
@@ -222,7 +226,18 @@ def cpu_baseline(ckpt, pyr1, pyr2, cfg):
             oracle_pair(ckpt, pyr1, pyr2, cfg["ptmax"], cfg["panc"], 0)
             times.append(time.perf_counter() - t0)
     t_pair = sorted(times)[len(times) // 2]
-    return {"value": 1.0 / t_pair, "unit": "pairs/s", "cores": threads, "kind": "port",
+    # what the UNMODIFIED reference would read: its time over the port's, both measured on the same cores of the build container
+    # (tools/cpu_reference_time.py; /root/reference does not exist on the GPU box, so the ratio is a committed record)
+    ratio = {}
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "cpu_reference_vs_port.json")))
+        ratio = {"reference_over_port": rec["reference_over_port"],
+                 "reference_equivalent_value": 1.0 / t_pair / rec["reference_over_port"],
+                 "reference_over_port_source": f"{rec['source']} ({rec['host']}, {rec['threads']} threads: reference "
+                                               f"{rec['reference_s_per_pair']} s, port {rec['port_s_per_pair']} s per pair)"}
+    except (OSError, KeyError, ValueError):
+        pass
+    return {**ratio, "value": 1.0 / t_pair, "unit": "pairs/s", "cores": threads, "kind": "port",
             "sample": f"1 warm-up + {reps} x one full {cfg['H']}x{cfg['W']} pair (coarse + filter ptmax={cfg['ptmax']} + mid/fine "
                       f"regressors on {cfg['ptmax'] * cfg['panc']} proposals), median {t_pair:.2f} s; torch-CPU fp32 port of the "
                       f"reference algorithm (oracle/p2p_oracle.py), {threads} threads ({os.cpu_count()} logical cores, CPU quota "
@@ -333,6 +348,14 @@ def roofline_of(mode, events):
                                      "three-product fp32-equivalent terms, and kernels that also move their operands sit at "
                                      "1.0-1.1 GHz of matrix-pipe issue against its 1.61 (profiles/r05_mfma_power_ceiling.txt, "
                                      "DESIGN.md section 4)")
+    if mode == "fp16x2w" and avg_ms > 0:
+        issued = sum(n * lv * ISSUED_FP16_FLOP_PER_PROPOSAL_LEVEL for _, _, n, lv in events) / max(len(events), 1)
+        out["issued_fp16_flop_per_launch"] = issued
+        out["issued_frac"] = issued / (avg_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS
+        out["issued_note"] = ("issued_frac = fp16 MFMA flop the call actually issues (conv1 with its cell-row de-duplication: 578.7 "
+                              "MFLOP, conv2 as Winograd F(2x2,3x3): 402.7 MFLOP per proposal and level; three products per fp32 "
+                              "product included) / time / 2500 TFLOP/s nominal: what the matrix pipe is asked to do, next to "
+                              "`frac`, which prices the DIRECT convolutions' flop count against 2500 / 3")
     if "kernels" in M:
         out["kernels"] = M["kernels"]
         out["note"] = ("the fine stage of one step = ONE p2p_regress_batch call = per regressor level and chunk of <= 2560 proposals "
@@ -424,6 +447,71 @@ def coarse_stage_ms(net, batch, reps=3):
         ev[1].record()
         torch.cuda.synchronize()
     return ev[0].elapsed_time(ev[1]) / reps / f1[4].shape[0]
+
+
+# algorithmic flop per pair of the two MFMA kernels of the coarse stage: correlation 2 nA nB 256; consensus
+# 4 layer applications x 2 x cells x 16 x 81
+def coarse_roofline(net, batch, config):
+    """Per-kernel roofline objects of the coarse stage.  nc_fused_kernel is timed LIVE (HIP events around
+    p2p_neigh_consensus_batch on the batch's pooled volumes: that call is exactly one launch of it); corr_pool_kernel has no
+    entry point of its own, its time comes from the rocprofv3 record of this source tree (profiles/kernel_times.json, keyed by
+    the hash of csrc/ like roofline.traffic; null when the sources changed since).  MFMA busy x clock from the PMC pass of the
+    same record."""
+    from patch2pix_amd import ops
+    f1, f2 = batch
+    B = f1[4].shape[0]
+    ha, wa = f1[4].shape[-2] // KSIZE, f1[4].shape[-1] // KSIZE
+    hb, wb = f2[4].shape[-2] // KSIZE, f2[4].shape[-1] // KSIZE
+    cells = ha * wa * hb * wb
+    flop_corr = 2.0 * (ha * wa * KSIZE * KSIZE) * (hb * wb * KSIZE * KSIZE) * f1[4].shape[1]
+    flop_nc = 4 * 2.0 * cells * 16 * 81
+    peak = PEAK_BF16_MFMA_TFLOPS / 3.0
+    out = {"peak": peak, "unit": "TFLOP/s", "bound": "mfma",
+           "peak_note": "2500 TFLOP/s dense fp16 MFMA / 3 MFMA products per fp32 product (both kernels compute in fp16x2)"}
+    with torch.no_grad():
+        corr, _ = net.forward_coarse_match(f1[4], f2[4], ksize=KSIZE)
+        x = corr.reshape(B, ha, wa, hb, wb).contiguous()
+        ncn = net._weights()[0]
+        for _ in range(2):
+            ops.neigh_consensus_batch(x, ncn)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        torch.cuda.synchronize()
+        reps = 5
+        ev[0].record()
+        for _ in range(reps):
+            ops.neigh_consensus_batch(x, ncn)
+        ev[1].record()
+        torch.cuda.synchronize()
+    nc_ms = ev[0].elapsed_time(ev[1]) / reps
+    out["nc_fused_kernel"] = {"avg_launch_ms": nc_ms, "pairs_per_launch": B, "algorithmic_flop_per_launch": flop_nc * B,
+                              "achieved": flop_nc * B / (nc_ms * 1e-3) / 1e12, "frac": flop_nc * B / (nc_ms * 1e-3) / 1e12 / peak,
+                              "timing": "live: HIP events around p2p_neigh_consensus_batch (one launch per call), alone on the GPU"}
+    rec = {}
+    try:
+        allrec = json.load(open(os.path.join(ROOT, "profiles", "kernel_times.json")))
+        rec = allrec.get(config, {})
+        if rec.get("source_hash") != source_hash():
+            rec = {}
+    except (OSError, ValueError):
+        pass
+    k = rec.get("kernels", {})
+    if "corr_pool_kernel" in k:
+        us = k["corr_pool_kernel"]["avg_us"]
+        out["corr_pool_kernel"] = {"avg_launch_ms": us / 1e3, "pairs_per_launch": rec.get("pairs_per_step"),
+                                   "algorithmic_flop_per_launch": flop_corr * rec.get("pairs_per_step", B),
+                                   "achieved": flop_corr * rec.get("pairs_per_step", B) / (us * 1e-6) / 1e12,
+                                   "frac": flop_corr * rec.get("pairs_per_step", B) / (us * 1e-6) / 1e12 / peak,
+                                   "timing": f"rocprofv3 kernel trace of bench.py inside the step ({rec.get('source')})"}
+    else:
+        out["corr_pool_kernel"] = None
+    for name in ("nc_fused_kernel", "corr_pool_kernel"):
+        if out.get(name) and name in k:
+            for f in ("mfma_busy_fraction", "effective_clock_ghz", "lds_bank_conflict_fraction"):
+                if k[name].get(f) is not None:
+                    out[name][f] = k[name][f]
+            if "nc_fused_kernel" == name:
+                out[name]["avg_us_inside_the_step"] = k[name]["avg_us"]
+    return out
 
 
 def config_leg(net, name, mode, rank, dev, steps=3, warmup=1):
@@ -692,6 +780,10 @@ def main():
     # ---- outside the timed region (single-GPU runs only) ----
     if rank == 0 and world == 1:
         out["coarse_stage_ms_per_pair"] = coarse_stage_ms(net, batches[0])
+        try:
+            out["coarse_roofline"] = coarse_roofline(net, batches[0], args.config)
+        except Exception as e:       # informational leg; never fail the bench line on it
+            out["coarse_roofline"] = {"error": repr(e)}
         if not args.no_parity:
             out["parity"] = parity_check(net, ckpt, batches[0], cpu_pairs, cfg)
         if not args.no_other_modes:

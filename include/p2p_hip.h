@@ -12,6 +12,12 @@
  *   - "device pointer" arguments are caller-owned HBM buffers (torch tensors); nothing is retained
  *     across calls except the opaque weight handles;
  *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - threading: every launch function is re-entrant per stream and may be called from several host threads (distinct
+ *     streams, or one stream with the caller's own ordering); the weight handles are immutable after creation
+ *     (p2p_regressor_set_mode / p2p_ncn_set_tile / p2p_conv_set_tile mutate a handle and must not race with launches that
+ *     use it).  The only process-wide state is a per-device "kernel attributes set" flag per launcher (dynamic-LDS size via
+ *     hipFuncSetAttribute, compute-unit count): atomic, set after idempotent work, so two threads meeting on a device's
+ *     first launch both do that work and neither sees a half-initialised value;
  *   - dense tensors are contiguous fp32 in the layout PyTorch produces (NCHW without the N);
  *   - match rows are (xA, yA, xB, yB).
  */

@@ -527,12 +527,12 @@ extern "C" void p2p_conv_destroy(p2p_conv *cv) {
 
 template <int MT, int NT, int WN, int NIT, int DB>
 static int launch_conv(const ConvArgs &a, dim3 grid, size_t lds, hipStream_t stream) {
-    static bool attr_set[64] = {false};
+    static DeviceOnce attr_set;
     int dev = 0;
     P2P_HIP_CHECK(hipGetDevice(&dev));
-    if (dev >= 64 || !attr_set[dev]) {
+    if (!attr_set.done(dev)) {
         P2P_HIP_CHECK(hipFuncSetAttribute((const void *)conv_kernel<MT, NT, WN, NIT, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        if (dev < 64) attr_set[dev] = true;
+        attr_set.set(dev);
     }
     hipLaunchKernelGGL((conv_kernel<MT, NT, WN, NIT, DB>), grid, dim3(256), lds, stream, a);
     return check_launch("conv_kernel");

@@ -69,6 +69,17 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
     if ((int)blockIdx.x * PREP_P >= h * w) return;
     const float *__restrict__ F = a.F[img] + blockIdx.z * a.sF[img];
     unsigned short *__restrict__ Fn = a.Fn[img] + blockIdx.z * a.sFn;
+    // The GEMM copies whole 128-row blocks: the rows between h * w and the next multiple of 128 are zeros, never uninitialised
+    // memory (its stores are masked, so their products were never used -- but NaN bit patterns went through the matrix cores).
+    // The work-group of the last positions writes them: <= 127 rows x C channels x 2 planes, 16 bytes per store.
+    if (((int)blockIdx.x + 1) * PREP_P >= h * w) {
+        const int pad0 = h * w, pad1 = (pad0 + 127) & ~127, pieces = (C >> 5) * 2 * 4;      // 16-byte pieces per row
+        for (int e = threadIdx.x; e < (pad1 - pad0) * pieces; e += 256) {
+            const int r = (pad0 + e / pieces) & 127, q = e % pieces, kc = q >> 3, pl = (q >> 2) & 1, piece = q & 3;
+            unsigned short *d = Fn + ((size_t)(pad0 >> 7) * (C >> 5) + kc) * (2 * 128 * 32) + pl * (128 * 32) + (r * 4 + piece) * 8;
+            *(f32x4 *)d = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
     __shared__ float tile[256 * (PREP_P + 1)];   // [C <= 256][17]
     __shared__ float part[16][PREP_P];
     __shared__ float inv[PREP_P];
@@ -676,11 +687,11 @@ extern "C" int p2p_coarse_forward_batch(const float *featA, const float *featB, 
     const int d0 = hA / ksize, d1 = wA / ksize, d2 = hB / ksize, d3 = wB / ksize;
     int dev = 0;
     P2P_HIP_CHECK(hipGetDevice(&dev));
-    static bool attr_set_dev[64] = {false};      // per device: a process may drive several GPUs
-    if (dev >= 64 || !attr_set_dev[dev]) {
+    static DeviceOnce attr_set_dev;      // per device: a process may drive several GPUs
+    if (!attr_set_dev.done(dev)) {
         P2P_HIP_CHECK(hipFuncSetAttribute((const void *)corr_pool_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS));
         P2P_HIP_CHECK(hipFuncSetAttribute((const void *)corr_pool_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS));
-        if (dev < 64) attr_set_dev[dev] = true;
+        attr_set_dev.set(dev);
     }
 
     for (int z0 = 0; z0 < batch; z0 += per_launch) {

@@ -698,11 +698,11 @@ int launch_nc_fused(const float *X, float *Y, float *Y2, size_t stride, int pair
                 "consensus tile does not fit (P %d, tc %d, LDS %zu)", a.P, a.tc, lds);
     int dev = 0;
     P2P_HIP_CHECK(hipGetDevice(&dev));
-    static bool attr_set[64] = {false};
-    if (dev >= 64 || !attr_set[dev]) {
+    static DeviceOnce attr_set;
+    if (!attr_set.done(dev)) {
         P2P_HIP_CHECK(hipFuncSetAttribute((const void *)nc_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         P2P_HIP_CHECK(hipFuncSetAttribute((const void *)nc_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        if (dev < 64) attr_set[dev] = true;
+        attr_set.set(dev);
     }
     if (a.tb == 5 && a.tc == 8 && a.td == 40 && a.P == 44)
         hipLaunchKernelGGL(nc_fused_kernel<true>, dim3(a.na * a.nb * a.nc * a.nd, 2, pairs), dim3(NCF_THREADS), lds, stream, a);

@@ -284,13 +284,13 @@ extern "C" int p2p_filter_coarse_batch(const int64_t *matches, const float *scor
     const size_t lds = big ? (size_t)FILTER_LDS_ROWS * 12 : (size_t)npad * 16;
     int dev = 0;
     P2P_HIP_CHECK(hipGetDevice(&dev));
-    static bool attr_set[64] = {false};      // per device: a process may drive several GPUs
-    if (dev >= 64 || !attr_set[dev]) {
+    static DeviceOnce attr_set;      // per device: a process may drive several GPUs
+    if (!attr_set.done(dev)) {
         P2P_HIP_CHECK(hipFuncSetAttribute((const void *)filter_coarse_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           FILTER_LDS_ROWS * 16));
         P2P_HIP_CHECK(hipFuncSetAttribute((const void *)filter_coarse_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           FILTER_LDS_ROWS * 12));
-        if (dev < 64) attr_set[dev] = true;
+        attr_set.set(dev);
     }
     FilterArgs a{(const long long *)matches, scores, n, npad, ncn_thres, mutual, (long long *)out_matches, out_scores, out_counts,
                  (unsigned char *)workspace};

@@ -1,6 +1,7 @@
 // Shared declarations for libp2p_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -88,6 +89,16 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 #endif
+
+// "Done once per device" flags of the launchers (hipFuncSetAttribute for a kernel's dynamic LDS size, the compute-unit count): the
+// work behind them is idempotent, so two host threads that meet on a device's first launch may both do it; the flag itself is an
+// atomic with release / acquire ordering, so a thread that sees it set also sees what was stored before it (include/p2p_hip.h,
+// threading note).
+struct DeviceOnce {
+    std::atomic<bool> flag[64];
+    bool done(int dev) const { return dev >= 0 && dev < 64 && flag[dev].load(std::memory_order_acquire); }
+    void set(int dev) { if (dev >= 0 && dev < 64) flag[dev].store(true, std::memory_order_release); }
+};
 
 // Check the launch that was just issued (asynchronous errors surface at the next sync).
 static inline int check_launch(const char *what) {

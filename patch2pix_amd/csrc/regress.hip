@@ -572,11 +572,11 @@ static int regress_batch_impl(const p2p_regressor *reg1, const p2p_regressor *re
     }
     int dev = 0;
     P2P_HIP_CHECK(hipGetDevice(&dev));
-    static bool attr_set[64] = {false};
-    if (dev < 64 && !attr_set[dev]) {
+    static DeviceOnce attr_set;
+    if (!attr_set.done(dev)) {
         P2P_HIP_CHECK(hipFuncSetAttribute((const void *)regress_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)LDS_BYTES));
-        attr_set[dev] = true;
+        attr_set.set(dev);
     }
     // launches of at most MAXB items; outputs/proposals are indexed by the global proposal number
     int first_prop = 0;

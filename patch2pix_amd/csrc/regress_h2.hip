@@ -1290,23 +1290,22 @@ void pack_h2_weights(const float *conv1_w, const float *conv2_w, float *wx1, flo
 static int launch_h2(const RegressArgs &a, int n, bool wino, hipStream_t stream) {
     int dev = 0;
     P2P_HIP_CHECK(hipGetDevice(&dev));
-    static bool attr_set[64] = {false};
-    static int cus[64] = {0};
-    if (dev >= 64 || !attr_set[dev]) {
+    static DeviceOnce attr_set;
+    static std::atomic<int> cus[64];
+    int ncu_dev = (dev >= 0 && dev < 64 && attr_set.done(dev)) ? cus[dev].load(std::memory_order_relaxed) : 0;
+    if (ncu_dev <= 0) {
         P2P_HIP_CHECK(hipFuncSetAttribute((const void *)regress_h2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)XSM_BYTES));
         P2P_HIP_CHECK(hipFuncSetAttribute((const void *)regress_h2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)XSM_BYTES));
-        int ncu = 0;
-        P2P_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        if (dev < 64) { cus[dev] = ncu; attr_set[dev] = true; }
-        else cus[0] = ncu;
+        P2P_HIP_CHECK(hipDeviceGetAttribute(&ncu_dev, hipDeviceAttributeMultiprocessorCount, dev));
+        if (dev >= 0 && dev < 64) { cus[dev].store(ncu_dev, std::memory_order_relaxed); attr_set.set(dev); }
     }
     // persistent work-groups: one fits a compute unit (LDS), each walks its share of the proposals
 #ifdef XF_GRID_CAP                       // power experiment: only this many work-groups (= busy compute units)
-    const int ncu = std::min(cus[dev < 64 ? dev : 0], XF_GRID_CAP);
+    const int ncu = std::min(ncu_dev, XF_GRID_CAP);
 #else
-    const int ncu = cus[dev < 64 ? dev : 0];
+    const int ncu = ncu_dev;
 #endif
     P2P_REQUIRE(a.ws, P2P_EINVAL, "%s: the scratch buffer is missing", "regress_h2_kernel");
     if (wino) hipLaunchKernelGGL(regress_h2_kernel<true>, dim3(std::min(n, std::max(ncu, 1))), dim3(NT), XSM_BYTES, stream, a);

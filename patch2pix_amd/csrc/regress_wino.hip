@@ -194,6 +194,31 @@ __global__ __launch_bounds__(WNT, 1) void wino_gemm_kernel(WinoArgs a) {
         }
 }
 
+// The GEMM copies whole 128-row blocks of the transformed input.  Rows of a block that no proposal owns (the tail of a chunk whose
+// size is no multiple of 8; with device-side counts, everything behind the last proposal of a partly filled block) are zeros,
+// never uninitialised memory: the GEMM's stores are masked, so their products were never used, but NaN bit patterns went through
+// the matrix cores.  One work-group per row block, before the conv1 launch of the chunk; blocks without such rows exit at once.
+__global__ __launch_bounds__(WNT) void wino_zero_tail_kernel(WinoArgs a, unsigned char *U, float *hinv, int p1) {
+    const int mb = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (wino_slot(a, a.p0 + mb * 8) < 0) return;          // an empty block: the GEMM skips it
+    for (int j = 1; j < 8; ++j) {
+        const int c = a.p0 + mb * 8 + j;
+        if (c < p1 && wino_slot(a, c) >= 0) continue;
+        // the 16 rows of proposal j of the block: lane = (tile, piece of 8 channels), wave w the K chunks 2 w and 2 w + 1
+        const unsigned rr = (unsigned)j * 16u + ((unsigned)lane >> 2);
+        const unsigned inblk = (rr * 4u + (((unsigned)lane & 3u) ^ ((rr >> 2) & 3u))) * 16u;
+        const size_t pstride = (size_t)a.mblocks * (16u * WINO_BLK);
+        for (int i2 = 0; i2 < 2; ++i2) {
+            unsigned char *ub = U + (size_t)(((unsigned)mb * 16u + (unsigned)(wave * 2 + i2)) * (unsigned)WINO_BLK + inblk);
+            for (int pos = 0; pos < 16; ++pos) {
+                *(uint4 *)(ub + pos * pstride) = make_uint4(0u, 0u, 0u, 0u);
+                *(uint4 *)(ub + pos * pstride + WINO_BLK / 2) = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+        if (tid == 0) hinv[mb * 8 + j] = 0.f;
+    }
+}
+
 // FC tail of a level as its own launch (the one-launch kernel runs it at the end of a work-group's share): same work
 // distribution, same code (fc_batch_parse, regress_common.h).
 __global__ __launch_bounds__(NT, 2) void regress_fc_kernel(RegressArgs args, int lvl) {
@@ -255,11 +280,11 @@ void pack_wino_weights(const float *conv2_w, float *out, int *t2) {
 int launch_regress_wino(RegressArgs a, int n, hipStream_t stream) {
     int dev = 0;
     P2P_HIP_CHECK(hipGetDevice(&dev));
-    static bool attr_set[64] = {false};
-    if (dev >= 64 || !attr_set[dev]) {
+    static DeviceOnce attr_set;
+    if (!attr_set.done(dev)) {
         P2P_HIP_CHECK(hipFuncSetAttribute((const void *)wino_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WLDS));
         P2P_HIP_CHECK(hipFuncSetAttribute((const void *)regress_fc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FC_LDS_BYTES));
-        if (dev < 64) attr_set[dev] = true;
+        attr_set.set(dev);
     }
     int ncu = 0;
     P2P_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -274,13 +299,23 @@ int launch_regress_wino(RegressArgs a, int n, hipStream_t stream) {
             const int cn = p1 - p0, mblocks = (cn + 7) / 8;
             if (cn <= 0) continue;
             a.lvl0 = lvl; a.p0 = p0; a.p1 = p0 + cn; a.wU = wsU; a.hinv = hinv; a.mblocks = mblocks;
-            int st = launch_regress_h2_conv1(a, cn, stream);
-            if (st != P2P_OK) return st;
             WinoArgs w;
             w.U = wsU; w.Wt = (const unsigned char *)a.reg[lvl].ww2; w.bn2s = a.reg[lvl].bn2s_w; w.bn2b = a.reg[lvl].bn2b;
             w.hinv = hinv; w.V = a.ws + (size_t)lvl * n * 512; w.mblocks = mblocks; w.p0 = p0; w.n = n;
             w.dev_counts = a.dev_counts; w.nitems = a.nitems;
             for (int b = 0; b <= MAXB; ++b) w.start[b] = a.start[b];
+            int st = P2P_OK;
+            if (a.dev_counts || (cn & 7)) {      // rows of a partly filled row block that no proposal owns: zeros (host counts: the last block only)
+                const int mb0 = a.dev_counts ? 0 : mblocks - 1;
+                WinoArgs wz = w;
+                wz.p0 = p0 + mb0 * 8;
+                hipLaunchKernelGGL(wino_zero_tail_kernel, dim3(mblocks - mb0), dim3(WNT), 0, stream, wz,
+                                   wsU + (size_t)mb0 * 16 * WINO_BLK, hinv + mb0 * 8, p0 + cn);
+                st = check_launch("wino_zero_tail_kernel");
+                if (st != P2P_OK) return st;
+            }
+            st = launch_regress_h2_conv1(a, cn, stream);
+            if (st != P2P_OK) return st;
             hipLaunchKernelGGL(wino_gemm_kernel, dim3(((mblocks + 7) / 8) * 32), dim3(WNT), WLDS, stream, w);
             st = check_launch("wino_gemm_kernel");
             if (st != P2P_OK) return st;

@@ -410,6 +410,45 @@ def test_batched_launch_equals_per_pair(dev, ops, weights):
             assert torch.equal(outs[i][k], single[k]), (i, k)
 
 
+def test_ragged_launches_are_bit_identical_per_proposal(dev, ops, weights):
+    """A proposal's result does not depend on what else is in the launch: counts that are no multiple of 8 (rows of a Winograd
+    row block that no proposal owns are zeros), of 16 (a partly filled FC batch), a single proposal -- every prefix of one
+    proposal list gives the first rows of the full launch, bit for bit."""
+    _, _, mid_w, fine_w = weights
+    H, W = 64, 96
+    g = torch.Generator().manual_seed(11)
+    pyr1, pyr2 = _gpu(synthetic.make_pyramid(410, H, W)[:4], dev), _gpu(synthetic.make_pyramid(411, H, W)[:4], dev)
+    n = 41
+    props = torch.stack([torch.randint(0, W + 1, (n,), generator=g), torch.randint(0, H + 1, (n,), generator=g),
+                         torch.randint(0, W + 1, (n,), generator=g), torch.randint(0, H + 1, (n,), generator=g)], 1).to(dev)
+    full = ops.regress(mid_w, fine_w, pyr1, pyr2, props)
+    for k in (1, 7, 8, 9, 13, 17, 40):
+        part = ops.regress(mid_w, fine_w, pyr1, pyr2, props[:k].contiguous())
+        for key in ("matches1", "probs1", "matches2", "probs2"):
+            assert torch.equal(part[key], full[key][:k]), (k, key)
+
+
+def test_many_items_and_more_proposals_than_a_chunk(dev, ops, weights):
+    """More items than one launch holds (18 > 16) AND more proposals than one chunk of the Winograd path (2 x 1500 + 16 x 40 >
+    2560): the launches of one call share the scratch with different offsets; results == one call per item."""
+    _, _, mid_w, fine_w = weights
+    if mid_w.mode == "f32":
+        pytest.skip("3640 proposals through the exact-f32 kernel: covered by the smaller batch tests")
+    g = torch.Generator().manual_seed(12)
+    sizes = [(48, 64)] * 18
+    counts = [1500, 1500] + [40] * 16
+    pyr1 = [_gpu(synthetic.make_pyramid(500 + i, H, W)[:4], dev) for i, (H, W) in enumerate(sizes)]
+    pyr2 = [_gpu(synthetic.make_pyramid(600 + i, H, W)[:4], dev) for i, (H, W) in enumerate(sizes)]
+    props = [torch.stack([torch.randint(0, W + 1, (c,), generator=g), torch.randint(0, H + 1, (c,), generator=g),
+                          torch.randint(0, W + 1, (c,), generator=g), torch.randint(0, H + 1, (c,), generator=g)], 1).to(dev)
+             for (H, W), c in zip(sizes, counts)]
+    outs = ops.regress_batch(mid_w, fine_w, pyr1, pyr2, props)
+    for i in (0, 1, 2, 15, 16, 17):
+        single = ops.regress(mid_w, fine_w, pyr1[i], pyr2[i], props[i])
+        for key in ("matches1", "probs1", "matches2", "probs2"):
+            assert torch.equal(outs[i][key], single[key]), (i, key)
+
+
 # ------------------------------------------------------------------------------------------ full sizes
 def _adjudicate_delta_flips(fa, fb, got, ref_code, ksize=2):
     """Every pooled cell whose relocalisation argmax differs from the fp32 oracle's is re-evaluated in fp64: the

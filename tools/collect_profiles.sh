@@ -13,6 +13,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 [ -f $ROOT/profiles/regress_traffic.json ] && [ ! -f $OUT/regress_traffic.json ] && cp $ROOT/profiles/regress_traffic.json $OUT/regress_traffic.json      # (a second call of one visit keeps the first one's records)
+[ -f $ROOT/profiles/kernel_times.json ] && [ ! -f $OUT/kernel_times.json ] && cp $ROOT/profiles/kernel_times.json $OUT/kernel_times.json
 # P2P_CONFIG=E profiles BASELINE configs[4] (960x1280, 2 pairs x 6400 proposals per step); files are tagged TAG_E_<mode>_*
 CFG=${P2P_CONFIG:-A}
 B="--no-cpu-baseline --no-parity --no-other-modes --no-e2e --no-other-configs --config $CFG"
@@ -27,5 +28,7 @@ for MODE in $MODES; do
   timeout 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/prof_p3 -o bench -- python $ROOT/bench.py --mode $MODE --steps 3 --warmup 1 $B > /dev/null 2>&1
   timeout 240 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY --kernel-trace -d /tmp/prof_p2 -o bench -- python $ROOT/bench.py --mode $MODE --steps 3 --warmup 1 $B > /dev/null 2>&1
   python $ROOT/tools/pmc_summary.py $OUT/${TAG}_${MODE}_pmc.txt $OUT/regress_traffic.json $MODE $(find /tmp/prof_p1 /tmp/prof_p2 /tmp/prof_p3 -name "*.db")
+  # per-kernel times + MFMA busy x clock of every p2p kernel of the step (bench.py: coarse_roofline), default mode only
+  [ "$MODE" = "fp16x2w" ] && python $ROOT/tools/kernel_times.py $OUT/kernel_times.json $CFG "profiles/${TAG}_${MODE}_kernel_stats.txt + profiles/${TAG}_${MODE}_pmc.txt" $(find /tmp/prof_k -name "*.db" | head -1) $(find /tmp/prof_p1 /tmp/prof_p2 /tmp/prof_p3 -name "*.db")
 done
 cat $OUT/regress_traffic.json

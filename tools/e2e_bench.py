@@ -14,6 +14,30 @@ from patch2pix_amd.utils import synthetic  # noqa: E402
 from patch2pix_amd.utils.eval import model_helper  # noqa: E402
 
 
+def producer_flop(net, H, W):
+    """2 x MACs of every Conv2d the pyramid producer runs for one H x W image (forward hooks on the torch module, CPU meta pass)."""
+    import torch.nn as nn
+    total = [0.0]
+
+    def hook(m, inp, outp):
+        total[0] += 2.0 * outp.numel() / outp.shape[0] * (m.in_channels // m.groups) * m.kernel_size[0] * m.kernel_size[1]
+    mods = [m for m in net.extract.modules() if isinstance(m, nn.Conv2d)]
+    hs = [m.register_forward_hook(hook) for m in mods]
+    prev = os.environ.get("P2P_BACKBONE")
+    try:
+        os.environ["P2P_BACKBONE"] = "miopen"            # the torch path of the same module: only shapes matter here
+        with torch.no_grad():
+            net.extract.pyramid(torch.zeros(1, 3, H, W, device=net.device))
+    finally:
+        for h in hs:
+            h.remove()
+        if prev is None:
+            os.environ.pop("P2P_BACKBONE", None)
+        else:
+            os.environ["P2P_BACKBONE"] = prev
+    return total[0]
+
+
 def measure(net, H=480, W=640, pairs=4, reps=3, stream_pairs=160):
     """-> {per_pair_pairs_per_s, stream_pairs_per_s, backbone_ms_per_image, ...}; jpeg inputs (quality 95)."""
     from patch2pix_amd.utils.eval.stream import estimate_matches_stream
@@ -100,6 +124,15 @@ def measure(net, H=480, W=640, pairs=4, reps=3, stream_pairs=160):
         return (time.perf_counter() - t0) / (reps * nb) * 1e3
     out["backbone_ms_per_image"] = producer_ms(2)
     out["backbone_ms_per_image_batch16"] = producer_ms(16)
+    # algorithmic work of the producer (conv1 ... layer3 of ResNet34 with the stride patch, networks/resnet.py:125-173): counted
+    # from the module's convolutions, 2 x output pixels x output channels x input channels x taps
+    flop = producer_flop(net, H, W)
+    ach = flop / (out["backbone_ms_per_image_batch16"] * 1e-3) / 1e12
+    out["producer_roofline"] = {"kernel": "conv_kernel (+ stem_kernel, maxpool_nhwc_kernel, nhwc_to_nchw_kernel)", "bound": "mfma",
+                                "algorithmic_flop_per_image": flop, "avg_ms_per_image_batch16": out["backbone_ms_per_image_batch16"],
+                                "achieved": ach, "peak": 2500.0 / 3.0, "unit": "TFLOP/s", "frac": ach / (2500.0 / 3.0),
+                                "note": "all 36 launches of one image's pyramid, batch of 16 images, wall clock / 16; fp16x2: three "
+                                        "MFMA products per fp32 product, peak = 2500 / 3"}
     prev = os.environ.get("P2P_BACKBONE")
     try:
         os.environ["P2P_BACKBONE"] = "miopen"
