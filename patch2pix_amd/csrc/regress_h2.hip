@@ -91,18 +91,24 @@ constexpr int XUB = XNPL * 1024;
 //            rows 0-3/12-15 of K quarter q take the even and rows 4-11 of quarter q + 1 the odd slots;
 //   the dead rows of a cell tile (and, in conv2, taps outside the 8 x 8 map) read zeros from the piece of a zero area that
 //   keeps them on the slot of their virtual row -- one shared zero cell collided with a live row in half of the groups.
-constexpr int XST1 = 64 * 4 + 16;                                 // bytes per level-1 cell (17 slots)
-constexpr int XRP1 = 9 * XST1 + 240;                              // level-1 grid row: 168 slots = 8 (mod 16)
+// level 1 (round 6): two fp16 planes like levels 2 / 3 -- [plane][9 grid rows][9 cells][64 ch (+16 B)]; a cell is 9 slots, a grid
+// row 88 slots = 8 (mod 16): the 16 lanes of a ds_read_b128 service group (4 y x 4 x of the tap's pixels) land on 16 different slots
+// ({0,9,2,11} + {0,8,..} ...: see "Bank slots"), as the fp32 grid of rounds 4-5 did with its 17-slot cells
+constexpr int XST1 = 64 * 2 + 16;                                 // bytes per level-1 cell (9 slots)
+constexpr int XRP1 = 9 * XST1 + 112;                              // level-1 grid row: 88 slots = 8 (mod 16)
+constexpr int XPL1 = 9 * XRP1;                                    // plane stride
 constexpr int YST2 = 64 * 2 + 16, YNC2 = 25, YPL2 = (YNC2 + 3) * YST2;  // level 2: cell stride, cells (+ 432 B of zeros), plane stride
 constexpr int YST3 = 128 * 2 + 32, YNC3 = 9, YPL3 = (YNC3 + 2) * YST3;  // level 3: 18 slots per cell (+ 576 B of zeros)
 constexpr int XOFF1 = 0;
-constexpr int YOFF2 = XOFF1 + 9 * XRP1;
+constexpr int YOFF2 = XOFF1 + XNPL * XPL1;
 constexpr int YOFF3 = YOFF2 + XNPL * YPL2;
 constexpr int XIMG = YOFF3 + XNPL * YPL3;
 constexpr int XRAW0 = 2 * XIMG;                                   // float [2][3][256]
 constexpr int XSHARED = XRAW0 + 2 * 3 * 256 * 4;
 constexpr int XTMP2ST = 64 * 4 + 16, XTMP3ST = 128 * 4 + 16;      // fp32 copy of levels 2/3: [25][272] then [9][528]
 constexpr int XTMP3 = YNC2 * XTMP2ST, XTMPIMG = XTMP3 + YNC3 * XTMP3ST;
+constexpr int XTMP1 = 2 * XTMPIMG, XTMP1ST = 64 * 4 + 16, XTMP1IMG = 81 * XTMP1ST;   // fp32 copy of level 1: [img][81 cells][64 ch (+16 B:
+                                                                  // the gather's lanes walk cells, 17 slots apart)], behind levels 2 / 3
 constexpr int XA0ST = 64 * 4 + 16;
 // exclusive turns of the two waves of a SIMD on the matrix pipe (see XPP / the conv1 protocol below): 1 = on.
 // conv2 (MFMA-bound, 43 B/clk of weights) gains 3 % from them; conv1 -- bound by its weight ingest, which needs every wave's
@@ -144,8 +150,8 @@ constexpr int XSM_BYTES = XSM_MISC + 16 * 4 + 8 * 16 * 4;
 constexpr int XSM_BYTES = XSM_MISC + 16 * 4;
 #endif
 static_assert(FC_LDS_BYTES <= XSM_MISC, "the FC batch stages its rows over the convolution buffers");
-static_assert(2 * XTMPIMG <= XSHR && 64 * XA0ST <= XSHR, "the shared region is sized by the fold buffers");
-static_assert(XIMG % 16 == 0 && YOFF2 % 16 == 0 && YOFF3 % 16 == 0 && YPL2 % 16 == 0 && YPL3 % 16 == 0 && XSHARED % 16 == 0 &&
+static_assert(XTMP1 + 2 * XTMP1IMG <= XSHR && 64 * XA0ST <= XSHR, "the shared region is sized by the fold buffers");
+static_assert(XPL1 % 16 == 0 && XTMP1 % 16 == 0 && XIMG % 16 == 0 && YOFF2 % 16 == 0 && YOFF3 % 16 == 0 && YPL2 % 16 == 0 && YPL3 % 16 == 0 && XSHARED % 16 == 0 &&
               XTAB % 16 == 0 && XSM_SCALE % 16 == 0 && HPL % 16 == 0 && HCHUNK % 16 == 0 && XCONV2B % 16 == 0,
               "16-byte alignment of ds_read_b128");
 static_assert(XSM_BYTES <= 160 * 1024, "LDS budget");
@@ -270,6 +276,34 @@ __device__ __forceinline__ void splitn(const f32x4 &xa, const f32x4 &xb, float s
       XHALF(acc10, acc11, S1, BC0, BC1) XPIPE0() __builtin_amdgcn_sched_barrier(0); }
 // start of a run of slabs: fragments of its first slab
 #define XPRO(P0, P1, SC0) { XLOADR(R0, P0) XLOADR(R1, P1) splitn(R0[0], R0[1], (SC0), S0); }
+
+// ---- conv1, level 1 (round 6): pixel rows of the pre-split cell planes -------------------------------------------
+// Until round 5 the level-1 operand (cell x per-pixel scale) was split in registers inside the loop: 80 VALU operations per 12
+// MFMAs kept the range at 0.63 of its MFMA issue.  Now the cells are split ONCE per proposal (x 2^e of their image, like levels
+// 2 / 3), a tap's 64 pixel rows are multiplied unscaled into two temporaries (m-tile 0 / 1), ONE n-tile at a time, and the
+// per-pixel scale is applied when they are added to the accumulators: acc[pixel][n] += table[pixel(tap)] * tp[pixel][n] (the
+// fold table's entry, zero for the padding ring).  Step j of a (tap, image) range consumes weight unit j = (n-tile j / 4,
+// slab j % 4) and loads unit j + 6 (the ring of eight); the A fragments of a slab are read twice (once per n-tile).
+#define XQHALF_(C0IN, C1IN, CU0, CU1, A0, A1, BU)                                        \
+    CU0 = XMFMA(A0[1], BU[0], C0IN); CU1 = XMFMA(A1[1], BU[0], C1IN);                    \
+    CU0 = XMFMA(A0[0], BU[1], CU0); CU1 = XMFMA(A1[0], BU[1], CU1);                      \
+    CU0 = XMFMA(A0[0], BU[0], CU0); CU1 = XMFMA(A1[0], BU[0], CU1);
+#define XQHALF(CU0, CU1, A0, A1, BU) XQHALF_(CU0, CU1, CU0, CU1, A0, A1, BU)
+#define XQHALFZ(CU0, CU1, A0, A1, BU) XQHALF_(zero16, zero16, CU0, CU1, A0, A1, BU)
+#define XQPIPE()                                                                         \
+    _Pragma("unroll") for (int g_ = 0; g_ < 2 * XNPL; ++g_) {                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }       \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, XNPL, 0);          \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#define XQSTEP(HALF, AC0, AC1, AN0, AN1, NP0, NP1, BC, BN, AH)                            \
+    { XLOADP(AN0, NP0, XPL1) XLOADP(AN1, NP1, XPL1) XLOADB(BN, AH)                                                    \
+      HALF(tp0, tp1, AC0, AC1, BC) XQPIPE() __builtin_amdgcn_sched_barrier(0); }
+// acc (m-tile 0 / 1 of one n-tile) += table entry of the register's pixel x tp
+#define XPFOLD(ACC0, ACC1)                                                               \
+    { _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) {                                                             \
+          const float e0_ = *(const float *)(tabq + ((2 * (r_ >> 2)) * 17 + 2 * (r_ & 3)) * 8);                       \
+          const float e1_ = *(const float *)(tabq + ((8 + 2 * (r_ >> 2)) * 17 + 2 * (r_ & 3)) * 8);                   \
+          ACC0[r_] = fmaf(e0_, tp0[r_], ACC0[r_]); ACC1[r_] = fmaf(e1_, tp1[r_], ACC1[r_]); } }
 
 // ---- slabs whose A operand was split beforehand ------------------------------------------------------
 #define XLPIPE(NDS, NMFMA)                                                               \
@@ -439,7 +473,6 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                     const int e = tv + k * NT;
                     if (e < 768) raw0[img * 768 + e] = gn0[img][k];
                 }
-                unsigned char *tb = smb + img * XIMG;
 #pragma unroll
                 for (int j = 1; j < 4; ++j) {
                     const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
@@ -452,7 +485,7 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                             const int c = e / (Rr * Rr);
                             const int rem = e - c * (Rr * Rr);
                             const float v = (j == 1) ? gn1[img][k] : (j == 2) ? gn2[img][k] : gn3[img][k];
-                            if (j == 1) *(float *)(tb + XOFF1 + (rem / 9) * XRP1 + (rem % 9) * XST1 + c * 4) = v;
+                            if (j == 1) *(float *)(smb + XSHARED + XTMP1 + img * XTMP1IMG + rem * XTMP1ST + c * 4) = v;
                             else *(float *)(smb + XSHARED + img * XTMPIMG + ((j == 2) ? rem * XTMP2ST : XTMP3 + rem * XTMP3ST) + c * 4) = v;
                         }
                     }
@@ -566,7 +599,6 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                     const int e = tidv + k * NT;
                     if (e < 768) raw0[img * 768 + e] = g0[img][k];
                 }
-                unsigned char *tb = smb + img * XIMG;
 #pragma unroll
                 for (int j = 1; j < 4; ++j) {
                     const int Rr = (j == 1) ? 9 : (j == 2) ? 5 : 3;
@@ -580,7 +612,7 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                             const int rem = e - c * (Rr * Rr);
                             const float v = (j == 1) ? g1[img][k] : (j == 2) ? g2[img][k] : g3[img][k];
                             if (j == 1) {
-                                *(float *)(tb + XOFF1 + (rem / 9) * XRP1 + (rem % 9) * XST1 + c * 4) = v;
+                                *(float *)(smb + XSHARED + XTMP1 + img * XTMP1IMG + rem * XTMP1ST + c * 4) = v;
                             } else {
                                 // fp32 copy for the scale pass + the planes (exact: v = p0 + p1 + p2)
                                 *(float *)(smb + XSHARED + img * XTMPIMG + ((j == 2) ? rem * XTMP2ST : XTMP3 + rem * XTMP3ST) + c * 4) = v;
@@ -607,7 +639,6 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
         int c23_keep;
         {
             const int img = tidv >> 8, pix = tidv & 255, py = pix >> 4, px = pix & 15;
-            const unsigned char *tb = smb + img * XIMG;
             float ss = 0.f;
             {
                 const float *p = raw0 + img * 768 + patch_cell(XY0(img), py, 0, I.H[img]) * 16 + patch_cell(XX0(img), px, 0, I.W[img]);
@@ -621,7 +652,7 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                 const int Cc = (j == 3) ? 128 : 64;
                 const int cjy = patch_cell(XY0(img), py, j, I.H[img]), cjx = patch_cell(XX0(img), px, j, I.W[img]);
                 const int cj = cjy * Rr + cjx;
-                const unsigned char *p = (j == 1) ? tb + XOFF1 + cjy * XRP1 + cjx * XST1
+                const unsigned char *p = (j == 1) ? smb + XSHARED + XTMP1 + img * XTMP1IMG + cj * XTMP1ST
                                                   : smb + XSHARED + img * XTMPIMG + ((j == 2) ? cj * XTMP2ST : XTMP3 + cj * XTMP3ST);
                 for (int c = 0; c < Cc; c += 4) {
                     const f32x4 v = *(const f32x4 *)(p + c * 4);
@@ -650,7 +681,23 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
             const int eb = clampi((((const int *)misc)[12 + img] >> 23) & 0xff, 13, 240);
             *(f32x2 *)(smb + XTAB + img * XTABIMG + ((py + 1) * 17 + px + 1) * 8) =
                 (f32x2){sc_keep * __int_as_float((254 - eb) << 23), __int_as_float(c23_keep)};
-            // planes of levels 2 and 3 from their fp32 copy: 2 x (25 x 64 + 9 x 128) values
+            // planes of levels 1, 2 and 3 from their fp32 copies.  Level 1: 2 x 81 x 32 channel PAIRS (one 4-byte store per plane)
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const int e = tidv + k * NT;
+                if (e < 2 * 2592) {
+                    const int im = (e >= 2592), r = e - im * 2592;
+                    const int ebi = clampi((((const int *)misc)[12 + im] >> 23) & 0xff, 13, 240);
+                    const float mul = __int_as_float((ebi + 12) << 23);
+                    const int cell = r >> 5, c2 = (r & 31) * 2, cy = cell / 9, cx = cell - 9 * cy;
+                    const f32x2 v = *(const f32x2 *)(smb + XSHARED + XTMP1 + im * XTMP1IMG + cell * XTMP1ST + c2 * 4);
+                    const unsigned h = pk_e(v[0] * mul, v[1] * mul);
+                    unsigned char *d = smb + im * XIMG + XOFF1 + cy * XRP1 + cx * XST1 + c2 * 2;
+                    *(unsigned *)d = h;
+                    *(unsigned *)(d + XPL1) = pk_e(v[0] * mul - pk_lo(h), v[1] * mul - pk_hi(h));
+                }
+            }
+            // levels 2 and 3: 2 x (25 x 64 + 9 x 128) values
 #pragma unroll
             for (int k = 0; k < 11; ++k) {
                 const int e = tidv + k * NT;
@@ -725,33 +772,40 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
 #pragma unroll 1
             for (int it = 0; it < 18 + stagger; ++it) {
                 const int pi = it - stagger;
-                if (pi >= 0) {      // ---- P(pi): level 1 (64 ch), pixel rows, split in registers
+                if (pi >= 0) {      // ---- P(pi): level 1 (64 ch), pixel rows of the pre-split cell planes
                     const int tap = pi >> 1, img = pi & 1;
                     const int ky = tap / 3, kx = tap - ky * 3;
-                    // this lane's pixel rows (LDS byte offsets per m-tile) and their scale (zero for the padding ring:
-                    // the product is then exactly zero)
+                    // this lane's pixel rows (LDS byte offsets per m-tile); a pixel of the padding ring reads some valid cell: its
+                    // table entry is zero
                     int ab[2];
-                    float sc[2];
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const int p = 32 * t + l31;
-                        const int py = 2 * (p >> 3) + ky - 1, px = 2 * (p & 7) + kx - 1;
-                        const bool ok = (py >= 0) && (px >= 0);
-                        const int pyc = max(py, 0), pxc = max(px, 0);
+                        const int pyc = max(2 * (p >> 3) + ky - 1, 0), pxc = max(2 * (p & 7) + kx - 1, 0);
                         ab[t] = img * XIMG + XOFF1 + patch_cell(XY0(img), pyc, 1, I.H[img]) * XRP1 +
-                                patch_cell(XX0(img), pxc, 1, I.W[img]) * XST1 + half * 32;
-                        sc[t] = ok ? scale[img * 256 + pyc * 16 + pxc] : 0.f;
+                                patch_cell(XX0(img), pxc, 1, I.W[img]) * XST1 + half * 16;
                     }
                     const unsigned char *a0 = smb + ab[0], *a1 = smb + ab[1];
+                    const unsigned char *tabq = smb + XTAB + img * XTABIMG + (ky * 17 + kx + 8 * half) * 8;
                     XPB_P0(stagger)
 #ifdef XF_SKIP_P                        // timing experiments (wrong results): XF_SKIP_P / _C / _FOLD / _CONV2 drop one part
-                    XWADV(8) (void)a0; (void)a1; (void)sc;
+                    XWADV(8) (void)a0; (void)a1; (void)tabq;
 #else
-                    XPRO(a0, a1, sc[0])
-                    XGROUP4(XSLAB(a0 + 64, a1 + 64, sc[0], sc[1], B0, B1, B6, B7, 6),
-                            XSLAB(a0 + 128, a1 + 128, sc[0], sc[1], B2, B3, B0, B1, 8),
-                            XSLAB(a0 + 192, a1 + 192, sc[0], sc[1], B4, B5, B2, B3, 10),
-                            XSLABEND(sc[1], B6, B7, B4, B5, 12))
+                    {
+                        f32x16 tp0, tp1;
+                        XLOADP(S0, a0, XPL1) XLOADP(S1, a1, XPL1)
+                        XQSTEP(XQHALFZ, S0, S1, R0, R1, a0 + 32, a1 + 32, B0, B6, 6)
+                        XQSTEP(XQHALF, R0, R1, S0, S1, a0 + 64, a1 + 64, B1, B7, 7)
+                        XQSTEP(XQHALF, S0, S1, R0, R1, a0 + 96, a1 + 96, B2, B0, 8)
+                        XQSTEP(XQHALF, R0, R1, S0, S1, a0, a1, B3, B1, 9)
+                        XPFOLD(acc00, acc10)
+                        XQSTEP(XQHALFZ, S0, S1, R0, R1, a0 + 32, a1 + 32, B4, B2, 10)
+                        XQSTEP(XQHALF, R0, R1, S0, S1, a0 + 64, a1 + 64, B5, B3, 11)
+                        XQSTEP(XQHALF, S0, S1, R0, R1, a0 + 96, a1 + 96, B6, B4, 12)
+                        XQSTEP(XQHALF, R0, R1, S0, S1, a0 + 96, a1 + 96, B7, B5, 13)
+                        XPFOLD(acc01, acc11)
+                        XWADV(8)
+                    }
 #endif
                     XPB_P1()
                     XTL(4)
@@ -1259,8 +1313,12 @@ void pack_h2_weights(const float *conv1_w, const float *conv2_w, float *wx1, flo
                     slab = 4 + step * 16 + 4 + (rel - 8);       // level-2 slab rel - 8
                 }
             }
+            // level 1 (canonical slabs 0-3 of a step): consumed one n-tile at a time -- unit 4 u + s of the range's 8 units is
+            // (n-tile u, slab s); everything else: units 2 pos + u
+            const bool lvl1 = slab >= 4 && (slab - 4) % 16 < 4;
+            const int s_in = lvl1 ? (slab - 4) % 16 : 0;
             for (int u = 0; u < 2; ++u) {
-                const int unit = pos * 2 + u;
+                const int unit = lvl1 ? (pos - s_in) * 2 + 4 * u + s_in : pos * 2 + u;
                 const size_t base = ((size_t)w * (S1_UNITS + XPF) + unit) * (XNPL * 64);
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
