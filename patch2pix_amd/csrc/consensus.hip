@@ -393,6 +393,11 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
                     }
             };
             frags(0, xv[0]);
+#ifndef NCF_NOPRIO                      // (A/B switch of tools/ab_variants.sh; experiment builds only)
+            // layer 1 is the MFMA-dense phase of a strip: its wave outranks the other wave of the SIMD (which is in an epilogue,
+            // a flush or layer 2's read-add-writes) for the issue slots; back to normal for the epilogue below (round 5: -2 %)
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int sl = 0; sl < 7; ++sl) {
                 nf4 (&c)[2][2] = xv[sl & 1];
@@ -411,6 +416,7 @@ __global__ __launch_bounds__(NCF_THREADS, 2) void nc_fused_kernel(NcFusedArgs a)
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_s_setprio(0);
             // bias, ReLU, zero outside the volume, scale, split: register r of a lane is channel r of its position
             // q0 + 2 (lane & 31) + (lane >> 5) -> one 16-byte store per channel half and plane
 #pragma unroll

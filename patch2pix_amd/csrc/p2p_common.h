@@ -9,16 +9,15 @@
 #include "../../include/p2p_hip.h"
 
 // Timing experiments (kernel variants that drop or pin a part of the work, phase stamps; most of them produce WRONG results
-// by design) exist only behind -DP2P_EXPERIMENT: such a build reports P2P_VERSION_EXPERIMENT in p2p_version() and the
+// by design; switches whose question is settled are retired once their ablation is logged under profiles/) exist only behind
+// -DP2P_EXPERIMENT: such a build reports P2P_VERSION_EXPERIMENT in p2p_version() and the
 // Python binding refuses to load it unless P2P_ALLOW_EXPERIMENT=1 is set (tools/ab_variants.sh does).  A product build with
 // one of the switches defined does not compile.
 #if !defined(P2P_EXPERIMENT) &&                                                                                          \
     (defined(XF_PIN_W) || defined(XF_SAME_PATCH) || defined(XF_SKIP_P) || defined(XF_SKIP_C) || defined(XF_SKIP_FOLD) ||   \
-     defined(XF_SKIP_CONV2) || defined(XF_CONV2_HALF) || defined(XF_SKIP_FC) || defined(XF_GRID_CAP) || defined(XF_TURN4) || \
-     defined(XF_WINO_NOSTORE) || defined(XF_WINO_NT) || defined(XF_WINO_STAGGER) || defined(P2P_WINO_CHUNK) || defined(XF_WINO_NOXF) || defined(XF_WINO_NOFOLD) || defined(XF_WINO_NODMA) ||           \
-     defined(P2P_X3_TIMING) || defined(NCF_TIMING) || defined(XF_TURNS1) || defined(XF_TURNS2) || defined(XP_VALU) || defined(XH_BURST) ||       \
-     defined(XH_NOSNAKE))
-#error "experiment switches (XF_*, XH_*, XP_*, P2P_X3_TIMING, NCF_TIMING, P2P_WINO_CHUNK) need -DP2P_EXPERIMENT: the library then identifies itself as an experiment build"
+     defined(XF_SKIP_CONV2) || defined(XF_SKIP_FC) || defined(XF_GRID_CAP) || defined(P2P_WINO_CHUNK) || defined(P2P_X3_TIMING) || \
+     defined(NCF_TIMING) || defined(NCF_NOPRIO))
+#error "experiment switches (XF_*, P2P_X3_TIMING, NCF_TIMING, NCF_NOPRIO, P2P_WINO_CHUNK) need -DP2P_EXPERIMENT: the library then identifies itself as an experiment build"
 #endif
 #define P2P_VERSION_EXPERIMENT 0x40000000
 

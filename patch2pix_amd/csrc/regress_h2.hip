@@ -110,21 +110,11 @@ constexpr int XTMP3 = YNC2 * XTMP2ST, XTMPIMG = XTMP3 + YNC3 * XTMP3ST;
 constexpr int XTMP1 = 2 * XTMPIMG, XTMP1ST = 64 * 4 + 16, XTMP1IMG = 81 * XTMP1ST;   // fp32 copy of level 1: [img][81 cells][64 ch (+16 B:
                                                                   // the gather's lanes walk cells, 17 slots apart)], behind levels 2 / 3
 constexpr int XA0ST = 64 * 4 + 16;
-// exclusive turns of the two waves of a SIMD on the matrix pipe (see XPP / the conv1 protocol below): 1 = on.
-// conv2 (MFMA-bound, 43 B/clk of weights) gains 3 % from them; conv1 -- bound by its weight ingest, which needs every wave's
-// loads in flight all the time -- loses 5 % of the launch to them (profiles/r04_ablation_log.txt), so its halves run free.
-#ifndef XF_TURNS1
-#define XF_TURNS1 0                     // conv1
-#endif
-#ifndef XF_TURNS2
-#define XF_TURNS2 1                     // conv2
-#endif
+// Exclusive turns of the two waves of a SIMD on the matrix pipe (XPP below): conv2 (MFMA-bound, 43 B/clk of weights) gains 3 %
+// from them; conv1 -- whose weight stream needs every wave's loads in flight all the time -- lost 5 % of the launch to them
+// (profiles/r04_ablation_log.txt), so its halves run free in a staggered order, every wave with a level-2 fold buffer of its own.
 constexpr int XTROW = 64 * 4;                                     // one fold-buffer row: 64 output channels of a wave, fp32
-#if XF_TURNS1
-constexpr int XTROWS = 28, XT2N = 4;      // level-2 buffer shared by waves w and w + 4 (their folds never overlap under the turn protocol)
-#else
-constexpr int XTROWS = 25, XT2N = 8;      // free-running waves: one buffer each, only the 25 rows that are read back
-#endif
+constexpr int XTROWS = 25, XT2N = 8;      // one level-2 buffer per wave, only the 25 rows that are read back
 constexpr int XTW = XTROWS * XTROW;                               // level-2 fold buffer
 constexpr int XSHR = XT2N * XTW + 8 * 9 * XTROW;                  // + T3[8 waves][9 level-3 rows]
 constexpr int XTAB = XSHARED + XSHR;
@@ -244,17 +234,14 @@ __device__ __forceinline__ void splitn(const f32x4 &xa, const f32x4 &xb, float s
 // sched_group_barrier pins the interleave (1 MFMA, then up to 4 VALU; the loads at the head of the phase).
 // Weights: (BC0, BC1) = this slab's two units, (BN0, BN1) = the next slab's, loaded one slab ahead (>= 768 matrix-pipe
 // cycles) into the buffers the previous slab used.
-#ifndef XP_VALU
-#define XP_VALU 6     // VALU operations placed behind each MFMA (tools/ab_variants.sh)
-#endif
 #define XPIPE(NDS)                                                                       \
     __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0); __builtin_amdgcn_sched_group_barrier(0x020, XNPL, 0);        \
     _Pragma("unroll") for (int g_ = 0; g_ < XNM; ++g_) {                                                              \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, XP_VALU, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); }
 #define XPIPE0()                                                                         \
     __builtin_amdgcn_sched_group_barrier(0x020, XNPL, 0);                                                             \
     _Pragma("unroll") for (int g_ = 0; g_ < XNM; ++g_) {                                                              \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, XP_VALU, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); }
 #define XSLAB(N0, N1, SC0, SC1, BC0, BC1, BN0, BN1, AH)                                   \
     { XLOADR(R0, N0) XLOADB(BN0, AH) splitn(R1[0], R1[1], (SC1), S1);                               \
       XHALF(acc00, acc01, S0, BC0, BC1) XPIPE(2) __builtin_amdgcn_sched_barrier(0);                                   \
@@ -333,36 +320,10 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // 85 % (measured); so the two halves of the work-group take turns, two slabs (48 MFMAs) at a time: XPP() = the two
 // barriers that end a wave's turn and its partner's (a bare s_barrier: outstanding loads stay in flight).
 #define XPB() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
-#if XF_TURNS2
 #define XPP() __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
-#else
-#define XPP()
-#endif
-#ifdef XF_TURN4                         // experiment: four slabs per turn in conv2
-#define XPP2()
-#else
-#define XPP2() XPP()
-#endif
-// conv1 barrier protocol per step (see the loop): P0 before / P1 after the pixel range, C0 before / C1 after the cell
-// range, F after the fold.  Exclusive turns with staggered halves (waves 0-3: P | - | C | F, waves 4-7: - | C | F | P), or
-// (XF_TURNS1 = 0) no barriers at all: the halves keep their staggered order and run free.
-#define XSTAGGER(g) (g)
-#if XF_TURNS1
-#define XPB_P0(st) if (st) XPB()
-#define XPB_P1() XPB()
-#define XPB_C0(g) XPB()
-#define XPB_C1(g) XPB()
-#define XPB_F(st, g) if (!(st)) XPB()
-#else
-#define XPB_P0(st)
-#define XPB_P1()
-#define XPB_C0(g)
-#define XPB_C1(g)
-#define XPB_F(st, g)
-#endif
-// (the MFMAs lead: the first ones issue as soon as the turn starts, the loads for later slabs follow in their shadow)
-#ifndef XH_BURST                        // one load behind every MFMA: 2-3 % faster than two bursts at the head (XH_BURST);
-                                        // global loads first, alternating LDS/global loads, one load per two MFMAs: no better
+// (the MFMAs lead: the first ones issue as soon as the turn starts, the loads for later slabs follow in their shadow -- one load
+// behind every MFMA measured 2-3 % faster than two bursts at the head; four slabs per turn, global loads first, alternating
+// LDS / global loads, one load per two MFMAs: no better; profiles/r03_ablation_log.txt, r04_ablation_log.txt)
 #define XHPIPE()                                                                         \
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                                \
     _Pragma("unroll") for (int g_ = 0; g_ < 2 * XNPL; ++g_) {                                                        \
@@ -370,22 +331,13 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
     _Pragma("unroll") for (int g_ = 0; g_ < 2 * XNPL; ++g_) {                                                        \
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }       \
     __builtin_amdgcn_sched_group_barrier(0x008, 4 * XNPROD - 4 * XNPL - 2, 0);
-#else
-#define XHPIPE()                                                                         \
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2 * XNPL, 0);      \
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 2 * XNPL, 0);      \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4 * XNPROD - 4, 0);
-#endif
-#ifndef XH_NOSNAKE                      // MFMA order in which consecutive instructions share one operand and the four
-                                        // accumulators rotate (0.5 % faster than m-tile after m-tile: XH_NOSNAKE)
+// MFMA order in which consecutive instructions share one operand and the four accumulators rotate (0.5 % faster than m-tile
+// after m-tile)
 #define XQUAD(AC0, AC1, BC0, BC1, P, Q)                                                  \
     acc00 = XMFMA(AC0[P], BC0[Q], acc00); acc01 = XMFMA(AC0[P], BC1[Q], acc01);                                       \
     acc11 = XMFMA(AC1[P], BC1[Q], acc11); acc10 = XMFMA(AC1[P], BC0[Q], acc10);
 #define XHMFMAS(AC0, AC1, BC0, BC1)                                                      \
     XQUAD(AC0, AC1, BC0, BC1, 1, 0) XQUAD(AC0, AC1, BC0, BC1, 0, 1) XQUAD(AC0, AC1, BC0, BC1, 0, 0)
-#else
-#define XHMFMAS(AC0, AC1, BC0, BC1) XHALF(acc00, acc01, AC0, BC0, BC1) XHALF(acc10, acc11, AC1, BC0, BC1)
-#endif
 #define XHSLAB(AC0, AC1, AN0, AN1, NP0, NP1, BC0, BC1, BN0, BN1, AH)                       \
     { XLOADP(AN0, NP0, HPL) XLOADP(AN1, NP1, HPL) XLOADB(BN0, AH) XLOADB(BN1, (AH) + 1)                                \
       XHMFMAS(AC0, AC1, BC0, BC1)                                                                                     \
@@ -405,9 +357,6 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwg = gridDim.x;
 
-#ifdef XF_WINO_STAGGER                   // timing experiment: start the work-groups in XF_WINO_STAGGER phases, XF_WINO_STAGGER_US apart
-    if (WINO) for (int i = 0; i < (int)((blockIdx.x >> 3) % XF_WINO_STAGGER) * (XF_WINO_STAGGER_US / 4); ++i) __builtin_amdgcn_s_sleep(127);
-#endif
     float *raw0 = (float *)(smb + XRAW0);
     float *scale = (float *)(smb + XSM_SCALE);
     float *misc = (float *)(smb + XSM_MISC);
@@ -768,7 +717,7 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
             // its fold.  In loop form: iteration it does P(it - stagger) then C(it) F(it).
             // The two halves also take turns on the matrix pipe (see XPP): per step, waves 0-3 run P | - | C | F and
             // waves 4-7 - | C | F | P between the same four barriers, so a fold always sits beside the partner's MFMAs.
-            const int stagger = XSTAGGER(wave >> 2), grp = wave >> 2; (void)grp;
+            const int stagger = wave >> 2;
 #pragma unroll 1
             for (int it = 0; it < 18 + stagger; ++it) {
                 const int pi = it - stagger;
@@ -787,7 +736,6 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                     }
                     const unsigned char *a0 = smb + ab[0], *a1 = smb + ab[1];
                     const unsigned char *tabq = smb + XTAB + img * XTABIMG + (ky * 17 + kx + 8 * half) * 8;
-                    XPB_P0(stagger)
 #ifdef XF_SKIP_P                        // timing experiments (wrong results): XF_SKIP_P / _C / _FOLD / _CONV2 drop one part
                     XWADV(8) (void)a0; (void)a1; (void)tabq;
 #else
@@ -807,7 +755,6 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                         XWADV(8)
                     }
 #endif
-                    XPB_P1()
                     XTL(4)
                 }
                 if (it < 18) {      // ---- C(it), F(it): levels 2 (64 ch) + 3 (128 ch), cell rows, pre-split planes
@@ -829,7 +776,6 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                     }
                     const unsigned char *q2 = smb + a2, *q3 = smb + a3;
                     f32x16 t0, t1;
-                    XPB_C0(grp)
 #if defined(XF_SKIP_C)
                     t0 = acc00; t1 = acc01; XWADV(24) (void)q2; (void)q3;
 #else
@@ -865,7 +811,6 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                                 XCSLAB(XHALF, S1, S0, q2 + 96, YPL2, B6, B7, B4, B5, 12))
                     }
 #endif
-                    XPB_C1(grp)
                     XTL(5)
 #ifndef XF_SKIP_FOLD
                     // fold: acc[pixel][n] += scale[pixel] * T[cell row of the pixel][n]
@@ -899,7 +844,6 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
 #else
                     acc00 += t0; acc01 += t1;
 #endif
-                    XPB_F(stagger, grp)
                     XTL(6)
                 }
             }
@@ -988,11 +932,7 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
             P2P_OPAQUE(tve);
             const int lq = tve & 63, oct = lq & 3, tile = lq >> 2, ty = tile >> 2, tx = tile & 3;
             const unsigned pl = (unsigned)(cprop - args.p0);
-#ifdef XF_WINO_NOSTORE                   // timing experiment (wrong results): every store of the transform lands in one 32 KB window
-            const unsigned pstride = 0;
-#else
             const unsigned pstride = (unsigned)args.mblocks * (16u * WINO_BLK);
-#endif
             const unsigned rr = (pl & 7u) * 16u + (unsigned)tile;
             const unsigned inblk = (rr * 4u + ((unsigned)oct ^ ((rr >> 2) & 3u))) * 16u;
             // LDS offset of window element (aa, bb) (outside the map: the zero row); recomputed where it is used -- a table of the 16
@@ -1001,17 +941,10 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                 const int y = 2 * ty + aa - 1, x = 2 * tx + bb - 1;
                 return (((unsigned)y < 8u && (unsigned)x < 8u) ? y * 8 + x : 64) * HWST + oct * 32;
             };
-#ifdef XF_WINO_NOXF                      // timing experiments (wrong results): no transform pass / no stores of its results
-            if (args.n < 0)
-#endif
 #pragma unroll 1
             for (int i2 = 0; i2 < 2; ++i2) {
                 const int kc = wave * 2 + i2;
-#ifdef XF_WINO_NOSTORE
-                unsigned char *ub = args.wU + (size_t)inblk;
-#else
                 unsigned char *ub = args.wU + (size_t)(((pl >> 3) * 16u + (unsigned)kc) * (unsigned)WINO_BLK + inblk);
-#endif
                 unsigned keep[16][4];                             // first pass: {h0a, h0b, h1a, h1b} of channels 0-3
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
@@ -1042,14 +975,8 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                                 kp[0] = h0a; kp[1] = h0b; kp[2] = h1a; kp[3] = h1b;
                             } else {
                                 unsigned char *dst = ub + (size_t)(ii * 4 + jj) * pstride;
-#ifdef XF_WINO_NT
-                                typedef unsigned nt_u4 __attribute__((ext_vector_type(4)));
-                                __builtin_nontemporal_store((nt_u4){kp[0], kp[1], h0a, h0b}, (nt_u4 *)dst);
-                                __builtin_nontemporal_store((nt_u4){kp[2], kp[3], h1a, h1b}, (nt_u4 *)(dst + WINO_BLK / 2));
-#else
                                 *(uint4 *)dst = make_uint4(kp[0], kp[1], h0a, h0b);
                                 *(uint4 *)(dst + WINO_BLK / 2) = make_uint4(kp[2], kp[3], h1a, h1b);
-#endif
                             }
                         }
                     }
@@ -1142,14 +1069,9 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                 const unsigned char *p0, *p1;
                 rows(0, p0, p1);
                 XLOADP(A00, p0, HPL) XLOADP(A01, p1, HPL)
-#if XF_TURNS2
                 if (wave >= 4) __builtin_amdgcn_s_barrier();        // waves 4-7 take the second turn
-#endif
 #ifdef XF_SKIP_CONV2
                 if (args.n < 0)
-#endif
-#ifdef XF_CONV2_HALF                    // timing experiment: only one wave per SIMD runs the conv2 loop
-                if (wave < 4)
 #endif
 #pragma unroll 1
                 for (int tap = 0; tap < 9; ++tap) {
@@ -1158,23 +1080,21 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                     // 8 slabs of 16 channels = 32 bytes per plane; slab j of a group of four loads the units of slab j + 3
                     XHSLAB(A00, A01, A10, A11, p0 + 32, p1 + 32, B0, B1, B6, B7, 6)
                     XHSLAB(A10, A11, A00, A01, p0 + 64, p1 + 64, B2, B3, B0, B1, 8)
-                    XPP2()
+                    XPP()
                     XHSLAB(A00, A01, A10, A11, p0 + 96, p1 + 96, B4, B5, B2, B3, 10)
                     XHSLAB(A10, A11, A00, A01, p0 + 128, p1 + 128, B6, B7, B4, B5, 12)
                     XPP()
                     XWADV(8)
                     XHSLAB(A00, A01, A10, A11, p0 + 160, p1 + 160, B0, B1, B6, B7, 6)
                     XHSLAB(A10, A11, A00, A01, p0 + 192, p1 + 192, B2, B3, B0, B1, 8)
-                    XPP2()
+                    XPP()
                     XHSLAB(A00, A01, A10, A11, p0 + 224, p1 + 224, B4, B5, B2, B3, 10)
                     XHSLAB(A10, A11, A00, A01, n0, n1, B6, B7, B4, B5, 12)
                     XPP()
                     XWADV(8)
                     p0 = n0; p1 = n1;
                 }
-#if XF_TURNS2
                 if (wave < 4) __builtin_amdgcn_s_barrier();         // every wave has executed the same number of barriers
-#endif
                 XT(10)
             }
         }

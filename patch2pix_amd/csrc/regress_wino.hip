@@ -147,9 +147,6 @@ __global__ __launch_bounds__(WNT, 1) void wino_gemm_kernel(WinoArgs a) {
             P2P_WAIT_VMCNT(4);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-#ifdef XF_WINO_NODMA                    // timing experiment (wrong results): the ring is never refilled
-            if (a.n < 0)
-#endif
             WISSUE(p * 16 + kc + 3, (kc + 3) & 3)
             // slab 1, behind it the reads of the next stage's slab 0
             WREAD(XA, XB, (kc + 1) & 3, 0)
@@ -157,9 +154,6 @@ __global__ __launch_bounds__(WNT, 1) void wino_gemm_kernel(WinoArgs a) {
             WPIPE_B()
         }
         // Y[a][b] += A^T[a][i] A^T[b][j] M,   A^T = [[1, 1, 1, 0], [0, 1, -1, -1]]
-#ifdef XF_WINO_NOFOLD                   // timing experiment (wrong results): only the last position is folded
-        if (p == 15)
-#endif
         {
             const int i = p >> 2, j = p & 3;
             const float ca[2] = {(i < 3) ? 1.f : 0.f, (i == 0) ? 0.f : (i == 1) ? 1.f : -1.f};

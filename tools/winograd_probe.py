@@ -19,16 +19,26 @@ BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], d
 AT = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float64)
 
 
-def winograd_conv(u, w, dtype):
-    """u [N,C,8,8], w [O,C,3,3] -> [N,O,8,8]; transforms and the 16 GEMMs in `dtype`."""
-    g, bt, at = G.to(dtype), BT.to(dtype), AT.to(dtype)
+# F(4x4, 3x3) (Lavin & Gray): 6 x 6 windows at stride 4, 36 GEMMs, 2.25 products per output instead of F(2x2)'s 4
+G4 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
+                   [0, 0, 1]], dtype=torch.float64)
+BT4 = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
+                    [0, 4, 0, -5, 0, 1]], dtype=torch.float64)
+AT4 = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=torch.float64)
+
+
+def winograd_conv(u, w, dtype, f4=False):
+    """u [N,C,8,8], w [O,C,3,3] -> [N,O,8,8]; input / output transforms and the GEMMs in `dtype`, the filter transform in
+    fp64 (it is done once, at pack time) and then rounded to `dtype`.  f4: F(4x4,3x3) instead of F(2x2,3x3)."""
+    g, bt, at = (G4, BT4, AT4) if f4 else (G, BT, AT)
+    win, step, m = (6, 4, 4) if f4 else (4, 2, 2)
     n, c = u.shape[:2]
     up = F.pad(u.to(dtype), (1, 1, 1, 1))                                    # 10 x 10
-    tiles = up.unfold(2, 4, 2).unfold(3, 4, 2)                               # [N,C,4,4,4,4]: tile (ty,tx), window 4x4
-    V = torch.einsum("ij,nctujk,lk->nctuil", bt, tiles, bt)                  # B^T d B
-    U = torch.einsum("ij,ocjk,lk->ocil", g, w.to(dtype), g)                  # G g G^T   [O,C,4,4]
-    M = torch.einsum("nctuil,ocil->notuil", V, U)                            # 16 GEMMs over c
-    Y = torch.einsum("ij,notujk,lk->notuil", at, M, at)                      # A^T m A   [N,O,4,4,2,2]
+    tiles = up.unfold(2, win, step).unfold(3, win, step)                     # [N,C,T,T,win,win]: tile (ty,tx)
+    V = torch.einsum("ij,nctujk,lk->nctuil", bt.to(dtype), tiles, bt.to(dtype))      # B^T d B
+    U = torch.einsum("ij,ocjk,lk->ocil", g, w.double(), g).to(dtype)         # G g G^T   [O,C,win,win]
+    M = torch.einsum("nctuil,ocil->notuil", V, U)                            # win^2 GEMMs over c
+    Y = torch.einsum("ij,notujk,lk->notuil", at.to(dtype), M, at.to(dtype))  # A^T m A   [N,O,T,T,m,m]
     return Y.permute(0, 1, 2, 4, 3, 5).reshape(n, -1, 8, 8)
 
 
@@ -46,8 +56,8 @@ def forward(f1, f2, p, dtype, conv2):
 
 def main(n=96):
     torch.set_num_threads(8)
-    print("setting: |coordinate error| in px against the fp64 evaluation, max over proposals: direct fp32 / Winograd fp32 "
-          "(+ conv2 output error relative to its rms)")
+    print("setting: |coordinate error| in px against the fp64 evaluation, max over proposals: direct fp32 / F(2x2,3x3) fp32 / "
+          "F(4x4,3x3) fp32 (+ conv2 output error relative to its rms)")
     for wscale, bnspread, fmag in ((1, 1, 1), (2, 1, 1), (1, 2, 1), (1, 1, 4), (2, 2, 4)):
         sd = synthetic.make_state_dict(0, backbone=False)
         for k in sd:
@@ -70,6 +80,7 @@ def main(n=96):
         e_dir = (coords(forward(f1, f2, mid_p, torch.float32, direct)) - coords(ref)).abs().max().item()
         e_win = (coords(forward(f1, f2, mid_p, torch.float32, lambda u, w: winograd_conv(u, w, torch.float32))) - coords(ref)).abs().max().item()
         e_w64 = (coords(forward(f1, f2, mid_p, torch.float64, lambda u, w: winograd_conv(u, w, torch.float64))) - coords(ref)).abs().max().item()
+        e_f4 = (coords(forward(f1, f2, mid_p, torch.float32, lambda u, w: winograd_conv(u, w, torch.float32, True))) - coords(ref)).abs().max().item()
         # conv2 alone
         q = {k: v.double() for k, v in mid_p.items()}
         u = orc._bn(F.conv2d(torch.cat([f1, f2], 1), q["conv.0.weight"], None, stride=2, padding=1), q, "conv.1", (1, -1, 1, 1))
@@ -77,8 +88,9 @@ def main(n=96):
         rms = c64.pow(2).mean().sqrt()
         c_dir = ((direct(u.float(), q["conv.2.weight"].float()).double() - c64).abs().max() / rms).item()
         c_win = ((winograd_conv(u, q["conv.2.weight"], torch.float32).double() - c64).abs().max() / rms).item()
-        print(f"weights x{wscale} bn^{bnspread} feats x{fmag}: {e_dir:.2e} / {e_win:.2e} px (Winograd in fp64: {e_w64:.1e});  "
-              f"conv2 max err / rms: direct {c_dir:.2e}, Winograd {c_win:.2e}", flush=True)
+        c_f4 = ((winograd_conv(u, q["conv.2.weight"], torch.float32, True).double() - c64).abs().max() / rms).item()
+        print(f"weights x{wscale} bn^{bnspread} feats x{fmag}: {e_dir:.2e} / {e_win:.2e} / {e_f4:.2e} px (F(2x2) in fp64: {e_w64:.1e});  "
+              f"conv2 max err / rms: direct {c_dir:.2e}, F(2x2) {c_win:.2e}, F(4x4) {c_f4:.2e}", flush=True)
 
 
 if __name__ == "__main__":
