@@ -15,6 +15,7 @@ if [ "$PART" = all ]; then
   bash tools/collect_profiles.sh $TAG fp16x2w 2>&1 | tail -6
   P2P_CONFIG=E bash tools/collect_profiles.sh $TAG fp16x2w 2>&1 | tail -6
   cp $OUT/regress_traffic.json $ROOT/profiles/regress_traffic.json      # (on the box: the bench line below then carries the traffic)
+  cp $OUT/kernel_times.json $ROOT/profiles/kernel_times.json
   cd $ROOT; timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" 2>&1 | tail -2
   for B in 1 16; do BATCH=$B timeout 120 python tools/coarse_bench.py 2>&1 | tail -1; done > $OUT/${TAG}_coarse_bench.txt; H=960 W=1280 BATCH=2 REPS=10 timeout 120 python tools/coarse_bench.py 2>&1 | tail -1 >> $OUT/${TAG}_coarse_bench.txt; cat $OUT/${TAG}_coarse_bench.txt
   cd $ROOT
