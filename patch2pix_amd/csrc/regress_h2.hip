@@ -707,7 +707,10 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
             const int c2y = (l31 < 25) ? l31 / 5 : 0, c2x = (l31 < 25) ? l31 - 5 * (l31 / 5) : 0;
             // T2 (level-2 rows): under the turn protocol shared by wave w and w + 4 (their folds never overlap: G1's is over
             // before e3, G0's runs between e3 and e4), else one per wave; T3 (9 level-3 rows) is private
-            float *Tw = (float *)(smb + XSHARED + (wave & (XT2N - 1)) * XTW) + l31;
+            // fold buffers of this wave, rows of 64 floats = its 64 output channels with the two n-tiles INTERLEAVED (channel n of
+            // the wave at float 2 (n & 31) + (n >> 5)): a lane's pair (n, n + 32) is one 8-byte LDS access (round 6: the fold read
+            // them as two 4-byte words, 5 LDS instructions per row and step instead of 3)
+            float *Tw = (float *)(smb + XSHARED + (wave & (XT2N - 1)) * XTW) + 2 * l31;
             float *T3w = (float *)(smb + XSHARED + XT2N * XTW + wave * (9 * XTROW));
             const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
             // The K-ranges (tap, image) are walked in 18 steps.  A step = the pixel slabs of level 1 (P), the cell slabs
@@ -796,13 +799,13 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                                 X16SLAB(X16HALF, u2, u3, S0, , B2, B3, B0, B1, 8),
                                 X16SLAB(X16HALF, u0, u1, S1, XLOADP(S0, q2, YPL2), B4, B5, B2, B3, 10),
                                 X16SLAB(X16HALF, u2, u3, S1, , B6, B7, B4, B5, 12))
-                        // T3[row = 4 * kb + r][column 16 * nt + l16]
+                        // T3[row = 4 * kb + r][column 16 * nt + l16 -> float 2 (column & 31) + (column >> 5)]: n-tiles 0 / 2 and 1 / 3 pair up
                         P2P_WAVE_SYNC();
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             if (4 * kb + r < 9) {
-                                float *d = T3w + (4 * kb + r) * 64 + l16;
-                                d[0] = u0[r]; d[16] = u1[r]; d[32] = u2[r]; d[48] = u3[r];
+                                f32x2 *d = (f32x2 *)(T3w + (4 * kb + r) * 64) + l16;
+                                d[0] = (f32x2){u0[r], u2[r]}; d[16] = (f32x2){u1[r], u3[r]};
                             }
                         // level 2: 4 slabs of 16 channels, rows = level-2 cells
                         XGROUP4(XCSLAB(XHALFZ, S0, S1, q2 + 32, YPL2, B0, B1, B6, B7, 6),
@@ -819,8 +822,7 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2);              // + 4 * half
                         if ((r < 12 || half == 0) && row + 4 * half < XTROWS) {
-                            Tw[(row + 4 * half) * 64] = t0[r];
-                            Tw[(row + 4 * half) * 64 + 32] = t1[r];
+                            *(f32x2 *)(Tw + (row + 4 * half) * 64) = (f32x2){t0[r], t1[r]};
                         }
                     }
                     P2P_WAVE_SYNC();
@@ -833,9 +835,9 @@ __global__ __launch_bounds__(NT, 2) void regress_h2_kernel(RegressArgs args) {
                             for (int r = 0; r < 16; ++r) {
                                 const f32x2 e = *(const f32x2 *)(tabp + ((8 * t + 2 * (r >> 2)) * 17 + 2 * (r & 3)) * 8);
                                 const int offs = __float_as_int(e[1]);
-                                const float *g = (const float *)(Tr + (offs & 0xffff));
-                                const float *h3 = (const float *)((const unsigned char *)(T3w + l31) + (offs >> 16));
-                                const float v0 = g[0] + h3[0], v1 = g[32] + h3[32];
+                                const f32x2 g = *(const f32x2 *)(Tr + (offs & 0xffff));
+                                const f32x2 h3 = *(const f32x2 *)((const unsigned char *)(T3w + 2 * l31) + (offs >> 16));
+                                const float v0 = g[0] + h3[0], v1 = g[1] + h3[1];
                                 if (t == 0) { acc00[r] = fmaf(e[0], v0, acc00[r]); acc01[r] = fmaf(e[0], v1, acc01[r]); }
                                 else        { acc10[r] = fmaf(e[0], v0, acc10[r]); acc11[r] = fmaf(e[0], v1, acc11[r]); }
                                 if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // four rows in flight, not all 32
