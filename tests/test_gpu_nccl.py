@@ -103,3 +103,27 @@ def test_pair_stream_exchanges_over_rccl(nccl_world1):
     # a stream whose only pair yields no rows: the exchange runs on empty device tensors
     rows, ids, done = run_pair_stream(1, 0, 1, 2, submit, finish, gather_every=2, device=dev)
     assert done == 1 and rows.shape == (0, 9) and ids.shape == (0,)
+
+
+def test_bench_under_the_launcher_with_one_rank():
+    """The driver's N > 1 command line with N = 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr
+    127.0.0.1 --master-port P bench.py --gpus 1 ...` -- the rendezvous comes from the launcher's environment (RANK / WORLD_SIZE /
+    MASTER_*), the process group is `nccl` on the rank's GPU, the JSON line says so."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["P2P_BENCH_SPINUP"] = "0.2"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--pairs-per-step", "2",
+           "--no-parity", "--no-other-modes", "--no-e2e", "--no-other-configs", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["steps"] == 2
+    assert out["dist"]["backend"] == "nccl" and out["dist"]["world"] == 1
+    assert len(out["per_rank_pairs_per_s"]) == 1
