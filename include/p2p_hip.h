@@ -91,7 +91,7 @@ void p2p_regressor_destroy(p2p_regressor *reg);
  *                      Winograd F(2x2, 3x3): 16 batched GEMMs over the transformed tiles of ALL proposals (2.25x fewer
  *                      matrix-core passes; the transforms are exact up to fp32 rounding, transformed filters computed in
  *                      fp64 at pack time) -- three launches per regressor level instead of one, and a larger scratch
- *                      buffer (the transformed conv2 input of up to 2048 proposals, 512 KiB each).
+ *                      buffer (the transformed conv2 input of a chunk of up to 2560 proposals, 512 KiB each).
  * New handles start in P2P_REGRESS_DEFAULT (the library reads no environment variables; the Python host layer maps
  * P2P_REGRESS_MODE onto p2p_regressor_set_mode).  Only the weight stream of the mode in use is packed and uploaded;
  * p2p_regressor_set_mode builds another mode's on its first selection (host-side packing + one upload).   */

@@ -14,9 +14,9 @@
 // whose error is <= 2^-24 |x| (two half-ulp roundings of 11-bit significands) PROVIDED neither plane leaves the normal
 // range of fp16 (2^-14 ... 65504).  That is what the power-of-two scales 2^s are for -- they are exact, and every one of
 // them is undone exactly by a later multiplication:
-//   * activations of conv1: the per-pixel L2-normalised patch values (|v| <= 1) times 2^12; the de-duplicated cell rows
-//     of levels 2 and 3 times 2^e of their image, e = 12 + floor(log2(smallest per-pixel scale)), so that every component
-//     is <= 2^12 -- the fold multiplies by scale[pixel] * 2^(12 - e) instead of scale[pixel];
+//   * activations of conv1: the per-pixel L2-normalised level-0 values (|v| <= 1) times 2^12; the cells of levels 1, 2 and
+//     3 times 2^e of their image, e = 12 + floor(log2(smallest per-pixel scale)), so that every component is <= 2^12 --
+//     their partial sums are multiplied by scale[pixel] * 2^(12 - e) instead of scale[pixel];
 //   * weights: per output channel the power of two that brings the largest weight to [2^11, 2^12) (at pack time; folded
 //     into the BatchNorm scale that follows);
 //   * H = BN1(conv1), the input of conv2: per proposal the power of two that brings max |H| to [2^12, 2^13) (a
@@ -37,8 +37,11 @@
 //     the partial sum T[cell row][n] is folded into the accumulators (acc[pixel][n] += scale[pixel] * T[row(pixel)][n],
 //     through LDS fold buffers).  Level 3 (3 x 3 cells) runs on 16-row tiles (v_mfma_f32_16x16x32_f16) into its own fold
 //     buffer T3, level 2 on a 32-row tile into T2: -24.8 % MFMAs against pixel rows.
-//   * conv1, levels 0 and 1 (no de-duplication possible at stride 2): fp32 in LDS, scaled and split in registers
-//     (40 VALU operations per 8 values), software-pipelined against the MFMAs of the other m-tile.
+//   * conv1, level 1 (no de-duplication possible at stride 2: a tap's 64 pixels touch 64 different cells): since round 6 also
+//     from planes split once per proposal (cells x 2^e); the tap's pixel rows are multiplied unscaled into temporaries, one
+//     n-tile at a time, and the per-pixel scale is applied when they are added to the accumulators (XQSTEP / XPFOLD below).
+//     Level 0 (3 channels, 4 slabs per proposal): a pre-scaled fp32 im2col block, split in registers (40 VALU operations
+//     per 8 values), software-pipelined against the MFMAs of the other m-tile.
 //   * conv2: its input H = BN1(conv1) is split into the planes ONCE per proposal, by the BN1 pass, straight into the
 //     four 128-channel K-chunks conv2 walks (two fp16 planes are as many bytes as fp32): no conversion passes, no
 //     work-group barrier inside conv2.  The conv2 loop has no VALU work at all.
@@ -73,20 +76,20 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int XUB = XNPL * 1024;
 
 // ---- LDS layout (bytes) --------------------------------------------------------------------------
-// conv1 phase, per image: level 1 as fp32 [9 grid rows (+240 B)][9 cells][64 ch (+16 B pad)]; levels 2 and 3 as two fp16 planes
-// [plane][25 cells + 432 B of zeros][64 ch (+16 B)] and [plane][9 cells + 576 B of zeros][128 ch (+32 B)] ("Bank slots" below).
-// Then level 0 raw [img][3][256] and one
-// shared region that is, in turn: the fp32 copy of levels 2/3 the scale pass reads; the pre-scaled level-0 im2col
+// conv1 phase, per image: level 1 as two fp16 planes [plane][9 grid rows (+112 B)][9 cells][64 ch (+16 B pad)]; levels 2 and 3 as
+// two fp16 planes [plane][25 cells + 432 B of zeros][64 ch (+16 B)] and [plane][9 cells + 576 B of zeros][128 ch (+32 B)] ("Bank
+// slots" below).  Then level 0 raw [img][3][256] and one
+// shared region that is, in turn: the fp32 copies of levels 1-3 the scale pass reads (and the planes are converted from); the pre-scaled level-0 im2col
 // block A0[64 px][64 K fp32 (+16 B)] (K = img*32 + tap*3 + c, 27 real per image); the fold buffers
-// T2[4 wave pairs][28 level-2 rows][64 n] and T3[8 waves][9 level-3 rows][64 n] fp32.  Then the fold table [img][17][17] of {scale, T row offset} (row/column 0 =
+// T2[8 waves][25 level-2 rows][64 n] and T3[8 waves][9 level-3 rows][64 n] fp32 (the two n-tiles of a wave interleaved).  Then the fold table [img][17][17] of {scale, T row offset} (row/column 0 =
 // the zero padding ring of the convolution) and the per-pixel scale [2][256].
 //
 // Bank slots.  ds_read_b128 is served in four groups of 16 lanes (lanes {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same
 // + 32); a group is conflict-free when its lanes hit 16 different 16-byte slots of the 256-byte bank row.  All A-fragment
 // reads have "lane & 31 = tile row, lane >> 5 = K half" (16-row tiles: lane & 15, lane >> 4), and the tile rows of a group
 // are 16 different values mod 16, so every layout below makes the slot a bijection of (row mod 16):
-//   level 1: the 9 x 9 cell grid with a row pitch of 8 (mod 16) slots -> slot = 8 y + x = tile row (a plain [81] array,
-//            pitch 9, put three pairs of lanes of every group on one slot);
+//   level 1: the 9 x 9 cell grid with 9-slot cells and a row pitch of 8 (mod 16) slots: the 4 y x 4 x pixels of a service group
+//            land on slots {0,9,2,11} + {0,12,4,8} = 16 different ones (a plain [81] array put pairs of lanes on one slot);
 //   level 2: cell stride 9 slots (odd); level 3 (16-row tiles, K quarter = lane >> 4): cell stride 2 slots (mod 16), so that
 //            rows 0-3/12-15 of K quarter q take the even and rows 4-11 of quarter q + 1 the odd slots;
 //   the dead rows of a cell tile (and, in conv2, taps outside the 8 x 8 map) read zeros from the piece of a zero area that

@@ -269,7 +269,8 @@ void pack_wino_weights(const float *conv2_w, float *out, int *t2) {
         }
 }
 
-// Both levels of a launch: per level, chunks of WINO_CHUNK proposals run conv1 -> U (regress_h2_kernel<true>) and the
+// Both levels of a launch: per level, chunks of whole units of 256 proposals (wino_nchunks / wino_chunk_range, at most WINO_CHUNK
+// each) run conv1 -> U (regress_h2_kernel<true>) and the
 // GEMMs (U -> V); then the level's FC tail, whose matches are the next level's proposals.
 int launch_regress_wino(RegressArgs a, int n, hipStream_t stream) {
     int dev = 0;
