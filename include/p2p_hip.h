@@ -91,7 +91,7 @@ void p2p_regressor_destroy(p2p_regressor *reg);
  *                      Winograd F(2x2, 3x3): 16 batched GEMMs over the transformed tiles of ALL proposals (2.25x fewer
  *                      matrix-core passes; the transforms are exact up to fp32 rounding, transformed filters computed in
  *                      fp64 at pack time) -- three launches per regressor level instead of one, and a larger scratch
- *                      buffer (the transformed conv2 input of a chunk of up to 2560 proposals, 512 KiB each).
+ *                      buffer (the transformed conv2 input of a chunk of up to 3328 proposals, 512 KiB each).
  * New handles start in P2P_REGRESS_DEFAULT (the library reads no environment variables; the Python host layer maps
  * P2P_REGRESS_MODE onto p2p_regressor_set_mode).  Only the weight stream of the mode in use is packed and uploaded;
  * p2p_regressor_set_mode builds another mode's on its first selection (host-side packing + one upload).   */
@@ -206,7 +206,7 @@ typedef struct p2p_pyramid {
  *               outside the call)                                                             */
 size_t p2p_regress_workspace_bytes(int n);
 /* The same for ONE arithmetic mode (p2p_regress_workspace_bytes is the largest of them = the default mode's):
- * P2P_REGRESS_FP16X2W  4 KB per proposal slot + 512 KiB per proposal of a chunk of at most 2560 (<= 1.34 GB: the value
+ * P2P_REGRESS_FP16X2W  4 KB per proposal slot + 512 KiB per proposal of a chunk of at most 3328 (<= 1.74 GB: the value
  *                      jumps from ~2 MB per proposal to that cap once n exceeds one chunk -- callers that run another
  *                      mode should size their buffer with this query, not with p2p_regress_workspace_bytes),
  * P2P_REGRESS_FP16X2   4 KB per proposal slot,   P2P_REGRESS_F32   0 (the buffer is ignored).                      */

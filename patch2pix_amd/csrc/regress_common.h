@@ -46,16 +46,17 @@ struct RegressArgs {
 // convolution features V [level][n][512] and the un-truncated mid matches [n][4] the fine level starts from
 constexpr int FC_ROWS = 16;             // proposals per FC batch = rows of a v_mfma_f32_16x16x4_f32 tile
 // P2P_REGRESS_FP16X2W appends: the inverse H scale per proposal of a chunk, and the transformed conv2 input of a chunk of at
-// most WINO_CHUNK (2560) proposals (16 positions x 16 tiles x 512 channels x 2 fp16 planes = 512 KiB per proposal), as the A
+// most WINO_CHUNK (3328) proposals (16 positions x 16 tiles x 512 channels x 2 fp16 planes = 512 KiB per proposal), as the A
 // blocks of wino_gemm_kernel: [position 16][row block of 8 proposals][K chunk 16][WINO_BLK bytes]
 constexpr int WINO_BLK = 16384;         // [plane 2][row 128][32 K] fp16
 #ifndef P2P_WINO_CHUNK
-#define P2P_WINO_CHUNK 2560
+#define P2P_WINO_CHUNK 3328
 #endif
 // Proposals per conv1 -> GEMM round.  A call's n proposals are cut into ceil(units / (WINO_CHUNK / 256)) chunks of whole
 // units of 256 proposals (= whole rounds of the persistent conv1 launch on 256 compute units, two rounds of the GEMM's
-// 128-row x 128-column work-groups), sizes as even as the units allow: 6400 -> 2304 + 2048 + 2048 (a fixed chunk of 2048
-// left a last launch of 256 proposals = a half-empty GEMM round and a full set of fixed per-launch costs).
+// 128-row x 128-column work-groups), sizes as even as the units allow: 6400 -> 3328 + 3072, 12800 -> 3328 + 3328 + 3072 + 3072
+// (round 5's fixed chunk of 2048 left a last launch of 256 proposals = a half-empty GEMM round and a full set of fixed
+// per-launch costs; caps measured in round 6, same box: 2048 13.51, 2560 13.50, 3328 13.40, 6656 13.43 ms per 6400 x 2 call).
 constexpr int WINO_CHUNK = P2P_WINO_CHUNK;
 static_assert(WINO_CHUNK % 256 == 0 && WINO_CHUNK >= 256, "chunks are whole units of 256 proposals");
 static inline int wino_nchunks(size_t n) {

@@ -429,8 +429,8 @@ def test_ragged_launches_are_bit_identical_per_proposal(dev, ops, weights):
 
 
 def test_many_items_and_more_proposals_than_a_chunk(dev, ops, weights):
-    """More items than one launch holds (18 > 16) AND more proposals than one chunk of the Winograd path (2 x 1500 + 16 x 40 >
-    2560): the launches of one call share the scratch with different offsets; results == one call per item."""
+    """More items than one launch holds (18 > 16) AND more proposals than one chunk of the Winograd path (2 x 1500 + 14 x 40 >
+    3328 in the first launch): the launches of one call share the scratch with different offsets; results == one call per item."""
     _, _, mid_w, fine_w = weights
     if mid_w.mode == "f32":
         pytest.skip("3640 proposals through the exact-f32 kernel: covered by the smaller batch tests")
