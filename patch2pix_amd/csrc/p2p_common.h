@@ -129,6 +129,7 @@ struct p2p_regressor {
     const float *wh1, *wh2;     // fp16x2: the same weights, scaled per output channel, split into two fp16 planes
     const float *bn1s_h, *bn2s_h;   // fp16x2: folded BN scales times the inverse of those weight (and activation) scales
     const float *ww2, *bn2s_w;      // fp16x2w: conv2 as Winograd-transformed filter blocks (regress_wino.hip) + its BN scale
+    const float *wh1_w, *bn1s_w;    // fp16x2w: conv1's fp16x2 stream and folded BN1 scale inside this mode's allocation (dev_w)
     int mode;                   // P2P_REGRESS_F32 | P2P_REGRESS_FP16X2 | P2P_REGRESS_FP16X2W
     const float *bn1s, *bn1b;   // folded BN scale/shift [512]
     const float *bn2s, *bn2b;   // [512]

@@ -365,16 +365,20 @@ static int ensure_mode(p2p_regressor *r, int mode) {
     auto al = [](size_t n) { return (n + 63) & ~size_t(63); };
     const float *c1 = r->conv1_w.data(), *c2 = r->conv2_w.data();
     if (mode == P2P_REGRESS_FP16X2W && !r->dev_w) {
-        const int st0 = ensure_mode(r, P2P_REGRESS_FP16X2);      // conv1 runs from the fp16x2 stream
-        if (st0 != P2P_OK) return st0;
-        const size_t ob2 = al(WW2_FLOATS);
-        std::vector<float> h(ob2 + 512, 0.f);
-        std::vector<int> t2(512);
+        // conv2 as Winograd filter blocks + conv1's fp16x2 stream (the same stream the direct mode runs, packed here on its own:
+        // the direct mode's conv2 stream -- 9.6 MB per regressor -- is neither packed nor uploaded for this mode)
+        const size_t ob2 = al(WW2_FLOATS), o1 = ob2 + 512, ob1 = o1 + al(WH1_FLOATS);
+        std::vector<float> h(ob1 + 512, 0.f);
+        std::vector<int> t1(512), t2(512);
         pack_wino_weights(c2, &h[0], t2.data());
-        for (int n = 0; n < 512; ++n) h[ob2 + n] = std::ldexp(r->bn2s_host[n], -t2[n]);
-        const int st = upload(h, &r->dev_w, "the Winograd filter blocks");
+        pack_h2_weights(c1, nullptr, &h[o1], nullptr, t1.data(), nullptr);
+        for (int n = 0; n < 512; ++n) {
+            h[ob2 + n] = std::ldexp(r->bn2s_host[n], -t2[n]);
+            h[ob1 + n] = std::ldexp(r->bn1s_host[n], -12 - t1[n]);      // conv1 accumulates 2^12 x 2^t1[n] x the true sum
+        }
+        const int st = upload(h, &r->dev_w, "the Winograd filter blocks and conv1's stream");
         if (st != P2P_OK) return st;
-        r->ww2 = r->dev_w; r->bn2s_w = r->dev_w + ob2;
+        r->ww2 = r->dev_w; r->bn2s_w = r->dev_w + ob2; r->wh1_w = r->dev_w + o1; r->bn1s_w = r->dev_w + ob1;
     } else if (mode == P2P_REGRESS_FP16X2 && !r->dev_h) {
         const size_t o1 = 0, o2 = al(WH1_FLOATS), ob1 = o2 + al(WH2_FLOATS), ob2 = ob1 + 512;
         std::vector<float> h(ob2 + 512, 0.f);
@@ -485,7 +489,7 @@ extern "C" int p2p_regressor_create(const p2p_regressor_params *p, p2p_regressor
     (void)hipGetDevice(&r->device);
     r->dev = dev;
     r->dev_p = r->dev_h = r->dev_w = nullptr;
-    r->ww2 = r->bn2s_w = r->wp1 = r->wp2 = r->wh1 = r->wh2 = r->bn1s_h = r->bn2s_h = nullptr;
+    r->ww2 = r->bn2s_w = r->wp1 = r->wp2 = r->wh1 = r->wh2 = r->bn1s_h = r->bn2s_h = r->wh1_w = r->bn1s_w = nullptr;
     r->conv1_w.assign(p->conv1_w, p->conv1_w + (size_t)512 * 518 * 9);      // host copies: another mode's stream is packed on demand
     r->conv2_w.assign(p->conv2_w, p->conv2_w + (size_t)512 * 512 * 9);
     r->bn1s_host.assign(&h[o_bn1s], &h[o_bn1s] + 512);
@@ -521,6 +525,7 @@ static RegDev to_dev(const p2p_regressor *r) {
     d.fc1t = r->fc1t; d.fc1b = r->fc1b; d.bnf1s = r->bnf1s; d.bnf1b = r->bnf1b;
     d.fc2t = r->fc2t; d.fc2b = r->fc2b; d.bnf2s = r->bnf2s; d.bnf2b = r->bnf2b; d.fc3 = r->fc3; d.fc3b = r->fc3b;
     d.fc1p = r->fc1p; d.fc2p = r->fc2p;
+    if (r->mode == P2P_REGRESS_FP16X2W) { d.wh1 = r->wh1_w; d.bn1s_h = r->bn1s_w; }      // conv1's stream of this mode's allocation
     return d;
 }
 

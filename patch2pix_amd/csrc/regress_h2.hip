@@ -1202,9 +1202,10 @@ static void channel_exponents(const float *w, int rows, int per_row, int *t) {
 }
 
 void pack_h2_weights(const float *conv1_w, const float *conv2_w, float *wx1, float *wx2, int *t1, int *t2) {
+    // conv2_w == nullptr: conv1's stream only (P2P_REGRESS_FP16X2W runs conv2 from the Winograd blocks of regress_wino.hip)
     uint16_t *d1 = (uint16_t *)wx1, *d2 = (uint16_t *)wx2;
     channel_exponents(conv1_w, 512, 518 * 9, t1);
-    channel_exponents(conv2_w, 512, 512 * 9, t2);
+    if (conv2_w) channel_exponents(conv2_w, 512, 512 * 9, t2);
     auto W1 = [&](int n, int ch, int tap) { return std::ldexp(conv1_w[((size_t)n * 518 + ch) * 9 + tap], t1[n]); };
     auto W2 = [&](int n, int ch, int tap) { return std::ldexp(conv2_w[((size_t)n * 512 + ch) * 9 + tap], t2[n]); };
     for (int w = 0; w < 8; ++w)
@@ -1254,7 +1255,7 @@ void pack_h2_weights(const float *conv1_w, const float *conv2_w, float *wx1, flo
                     }
             }
         }
-    for (int w = 0; w < 8; ++w)
+    for (int w = 0; conv2_w && w < 8; ++w)
         for (int slab = 0; slab < S2_SLABS; ++slab) {
             const int chunk = slab / 72, tap = (slab % 72) / 8, sin = slab % 8;
             for (int u = 0; u < 2; ++u) {
