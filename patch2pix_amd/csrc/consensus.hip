@@ -644,24 +644,41 @@ size_t nc_fused_lds_bytes(int tb, int tc, int P) {
     return (size_t)2 * ((9 * (tc + 4) * P * 2 + 8 + 15) & ~15) + (size_t)2 * 2 * nc_hidden_slots(tc, P) * 16 + (size_t)3 * tb * nc_yrow(tc, P) * 4 + 256;
 }
 
-// float bits of max |x| over n values per pair -> out[pair * out_stride] (zero beforehand); one atomic per wave
+// float bits of max |x| over n values per pair -> out[pair * out_stride] (zero beforehand); one atomic per work-group, <= 256
+// work-groups per pair with four 16-byte loads in flight per thread (the per-wave probes of thousands of small work-groups
+// queued on the one cache line that holds a batch's results)
 __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, size_t n, size_t stride, int *out, size_t out_stride) {
+    __shared__ float part[4];
     x += (size_t)blockIdx.z * stride;
     float m = 0.f;
     const size_t n4 = (((size_t)x & 15) == 0) ? n >> 2 : 0;          // 16-byte loads where the item starts aligned
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const size_t step = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * step < n4; i += 4 * step) {
+        const nf4 v0 = ((const nf4 *)x)[i], v1 = ((const nf4 *)x)[i + step], v2 = ((const nf4 *)x)[i + 2 * step], v3 = ((const nf4 *)x)[i + 3 * step];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v0[0]), fabsf(v0[1]))), fmaxf(fabsf(v0[2]), fabsf(v0[3])));
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v1[0]), fabsf(v1[1]))), fmaxf(fabsf(v1[2]), fabsf(v1[3])));
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v2[0]), fabsf(v2[1]))), fmaxf(fabsf(v2[2]), fabsf(v2[3])));
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v3[0]), fabsf(v3[1]))), fmaxf(fabsf(v3[2]), fabsf(v3[3])));
+    }
+    for (; i < n4; i += step) {
         const nf4 v = ((const nf4 *)x)[i];
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
-    for (size_t i = 4 * n4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    for (size_t j = 4 * n4 + (size_t)blockIdx.x * 256 + threadIdx.x; j < n; j += step) m = fmaxf(m, fabsf(x[j]));
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-    int *dst = out + (size_t)blockIdx.z * out_stride;
-    if ((threadIdx.x & 63) == 0 && __float_as_int(m) > *(volatile int *)dst) atomicMax(dst, __float_as_int(m));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float mm = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+        int *dst = out + (size_t)blockIdx.z * out_stride;
+        if (__float_as_int(mm) > *(volatile int *)dst) atomicMax(dst, __float_as_int(mm));
+    }
 }
 
 int launch_absmax(const float *x, size_t n, size_t stride, int pairs, int *out, size_t out_stride, hipStream_t stream) {
-    const unsigned blocks = (unsigned)std::min<size_t>((n + 4095) / 4096, 1024);
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 16383) / 16384, 256);
     hipLaunchKernelGGL(absmax_kernel, dim3(blocks, 1, pairs), dim3(256), 0, stream, x, n, stride, out, out_stride);
     return check_launch("absmax_kernel");
 }
